@@ -1,0 +1,132 @@
+"""Seeded input recipes shared by tests/golden/make_golden.py (which feeds them to the
+reference) and by the tests (which feed the same inputs to the oracle and to the HIP path).
+
+All randomness comes from torch's CPU generator with explicit seeds, so the container and the
+GPU box (same image, same torch build) re-create identical inputs.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _unit(gen, *shape):
+    return F.normalize(torch.randn(*shape, generator=gen), dim=-1)
+
+
+def _bf16r(x):
+    return x.bfloat16().float()
+
+
+SMALL_CHUNK = {"small_ragged": 128, "lq1": 2, "chunk_tail": 3}
+
+
+def small_case(name):
+    """Small A1 cases with bf16-representable values (usable by the bf16 and the fp32 path)."""
+    if name == "small_ragged":
+        gen = torch.Generator().manual_seed(1234)
+        Q = _bf16r(_unit(gen, 4, 8, 128))
+        P = _bf16r(_unit(gen, 8, 40, 128))
+        qm = torch.ones(4, 8, dtype=torch.bool)
+        qm[1, 5:] = False
+        qm[3, :2] = False
+        pm = torch.ones(8, 40, dtype=torch.bool)
+        pm[2] = False                       # all-masked page -> score exactly 0, grad 0
+        pm[5, 25:] = False                  # suffix padding
+        pm[6, 3:30:4] = False               # holes in the middle
+        pm[7, :10] = False                  # masked prefix
+        P[1, 7] = P[1, 3]                   # duplicate patch -> tie, first index must win
+        P[1, 30] = P[1, 3]
+        g = torch.randn(4, 8, generator=gen)
+    elif name == "lq1":
+        gen = torch.Generator().manual_seed(4321)
+        Q = _bf16r(_unit(gen, 6, 1, 128))
+        P = _bf16r(_unit(gen, 5, 33, 128))
+        qm = torch.ones(6, 1, dtype=torch.bool)
+        qm[4, 0] = False
+        pm = torch.ones(5, 33, dtype=torch.bool)
+        pm[0, 32] = False
+        g = torch.randn(6, 5, generator=gen)
+    elif name == "chunk_tail":
+        gen = torch.Generator().manual_seed(99)
+        Q = _bf16r(_unit(gen, 3, 5, 128))
+        P = _bf16r(_unit(gen, 7, 20, 128))
+        qm = torch.ones(3, 5, dtype=torch.bool)
+        pm = torch.ones(7, 20, dtype=torch.bool)
+        pm[6, 10:] = False
+        g = torch.randn(3, 7, generator=gen)
+    else:
+        raise KeyError(name)
+    return Q, P, qm, pm, g
+
+
+def seeded_1030(bf16_inputs: bool):
+    """SURVEY §8(c) pin (1): torch.manual_seed(0); (8,32,128) x (64,1030,128)."""
+    gen = torch.Generator().manual_seed(0)
+    Q = _unit(gen, 8, 32, 128)
+    P = _unit(gen, 64, 1030, 128)
+    if bf16_inputs:
+        Q, P = _bf16r(Q), _bf16r(P)
+    qm = torch.ones(8, 32, dtype=torch.bool)
+    qm[:, 20:] = False
+    pm = torch.ones(64, 1030, dtype=torch.bool)
+    pm[3] = False
+    pm[5, 500:] = False
+    return Q, P, qm, pm
+
+
+def l2_case():
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(5, 9, 128, generator=gen) * 3.0
+    x[0, 0] = 0.0            # zero row stays exactly zero
+    x[2, 4] = 1e-20          # tiny row: eps is added to the norm, not clamped
+    return x
+
+
+def infonce_case():
+    gen = torch.Generator().manual_seed(11)
+    ss = torch.randn(32, 500, generator=gen) * 2.0 + 9.0
+    st = torch.randn(32, 500, generator=gen) * 2.0 + 9.0
+    return ss, st
+
+
+def train_case(tag):
+    """A7 capture: (Qb, qmb, P_teacher_raw, pmask_t, Pbar0_raw, pmask_s, hyper-params)."""
+    if tag == "b4n8":
+        B, N, Ls, Lt, seed = 4, 8, 40, 1030, 2024
+    elif tag == "b32n128":
+        B, N, Ls, Lt, seed = 32, 128, 206, 1030, 2025
+    else:
+        raise KeyError(tag)
+    gen = torch.Generator().manual_seed(seed)
+    Qb = _unit(gen, B, 32, 128)
+    qmb = torch.ones(B, 32, dtype=torch.bool)
+    qmb[:, 26:] = False
+    qmb[0, 10:] = False
+    Pt = torch.randn(N, Lt, 128, generator=gen)
+    pmt = torch.ones(N, Lt, dtype=torch.bool)
+    pmt[:, :4] = False                      # text-prefix tokens masked by the image mask
+    pmt[1, 700:] = False
+    # student init: block means of the teacher + noise (compressed pages), ragged lengths
+    blk = Lt // Ls
+    Pbar0 = Pt[:, : blk * Ls].reshape(N, Ls, blk, 128).mean(2) + 0.05 * torch.randn(N, Ls, 128, generator=gen)
+    pms = torch.ones(N, Ls, dtype=torch.bool)
+    pms[2, Ls - 7:] = False
+    pms[N - 1, Ls // 2:] = False
+    hp = {"temp": 0.1, "lr": 1e-3, "wd": 1e-2}
+    return Qb, qmb, Pt, pmt, Pbar0, pms, hp
+
+
+def single_vector_case():
+    gen = torch.Generator().manual_seed(5)
+    qs = [torch.randn(128, generator=gen) for _ in range(7)]
+    ps = [torch.randn(128, generator=gen) for _ in range(11)]
+    return qs, ps
+
+
+def ragged_lists_case():
+    """A2: ragged lists, bf16-representable, lengths chosen so every 4-batch has padding."""
+    gen = torch.Generator().manual_seed(17)
+    qlens = [5, 9, 12, 7, 3, 12]
+    plens = [33, 1, 17, 40, 25, 64, 8, 31, 2]
+    qs = [_bf16r(_unit(gen, l, 128)) for l in qlens]
+    ps = [_bf16r(_unit(gen, l, 128)) for l in plens]
+    return qs, ps

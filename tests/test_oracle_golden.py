@@ -1,0 +1,119 @@
+"""Pin the CPU oracle against fixtures produced by the reference's own functions
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import golden_recipes as R
+from oracle import maxsim_oracle as O
+
+
+def T(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+@pytest.mark.parametrize("case", ["small_ragged", "lq1", "chunk_tail"])
+def test_a1_small_forward_backward(golden, case):
+    z = golden(f"a1_{case}")
+    Q, P, qm, pm, g = R.small_case(case)
+    # the recipe re-creates exactly what the reference was fed
+    assert torch.equal(Q, T(z["Q"])) and torch.equal(P, T(z["P"]))
+    assert torch.equal(qm, T(z["qmask"])) and torch.equal(pm, T(z["pmask"]))
+    s = O.maxsim_masked(Q, P, qm, pm, chunk_p=R.SMALL_CHUNK[case])
+    np.testing.assert_allclose(s.numpy(), z["scores"], atol=2e-6, rtol=0)
+    s2, arg = O.maxsim_masked_argmax(Q, P, qm, pm)
+    np.testing.assert_allclose(s2.numpy(), z["scores"], atol=2e-6, rtol=0)
+    assert np.array_equal(arg.numpy().astype(np.int32), z["argmax"])
+    dP = O.maxsim_backward(g, Q, P, qm, pm)
+    np.testing.assert_allclose(dP.numpy(), z["dP"], atol=1e-6, rtol=0)
+    # autograd through the oracle agrees too
+    Pg = P.clone().requires_grad_(True)
+    (O.maxsim_masked(Q, Pg, qm, pm) * g).sum().backward()
+    np.testing.assert_allclose(Pg.grad.numpy(), z["dP"], atol=1e-6, rtol=0)
+
+
+def test_a1_known_answers(golden):
+    z = golden("a1_small_ragged")
+    Q, P, qm, pm, g = R.small_case("small_ragged")
+    s = z["scores"]
+    assert np.all(s[:, 2] == 0.0)                      # all-masked page -> exactly 0
+    assert np.all(z["dP"][2] == 0.0)                   # and exactly zero gradient
+    assert np.all(z["dP"][~pm.numpy()] == 0.0)         # masked positions never get gradient
+    # duplicate patches 3 / 7 / 30 of page 1: only the first may be selected
+    arg = z["argmax"][:, 1, :]
+    assert not np.any(arg == 7) and not np.any(arg == 30)
+
+
+@pytest.mark.parametrize("tag,bf16", [("f32", False), ("bf16", True)])
+def test_a1_seeded_1030(golden, tag, bf16):
+    z = golden("a1_seeded1030_" + tag)
+    Q, P, qm, pm = R.seeded_1030(bf16_inputs=bf16)
+    s = O.maxsim_masked(Q, P, qm, pm, chunk_p=64)
+    np.testing.assert_allclose(s.numpy(), z["scores"], atol=5e-6, rtol=0)
+    if not bf16:  # SURVEY §8(c) pin (1)
+        np.testing.assert_allclose(z["scores"][0, :6], [5.7109, 5.7141, 5.6196, 0.0, 5.6686, 5.1231], atol=1e-4)
+
+
+def test_a4_l2_normalize(golden):
+    z = golden("a4_l2norm")
+    y = O.l2_normalize(T(z["x"]))
+    np.testing.assert_allclose(y.numpy(), z["y"], atol=1e-7, rtol=1e-6)
+    assert np.all(z["y"][0, 0] == 0.0)
+
+
+def test_a5_infonce(golden):
+    z = golden("a5_infonce")
+    ss, st = T(z["score_s"]), T(z["score_t"])
+    loss = O.infonce_distill(ss, st, float(z["temp"]))
+    np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=1e-6)
+    np.testing.assert_allclose(O.infonce_distill_grad(ss, st, float(z["temp"])).numpy(), z["dscore"], atol=1e-7)
+
+
+def test_a7_train_step_small(golden):
+    z = golden("a7_step_b4n8")
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = R.train_case("b4n8")
+    Ptn = O.l2_normalize(Pt * pmt.unsqueeze(-1))
+    loss, grad, after, sc_t, sc_s = O.distill_train_step(
+        Qb, qmb, Ptn, pmt, Pbar0 * pms.unsqueeze(-1), pms, hp["temp"], hp["lr"], hp["wd"])
+    np.testing.assert_allclose(sc_t.numpy(), z["sc_t"], atol=5e-6)
+    np.testing.assert_allclose(sc_s.numpy(), z["sc_s"], atol=5e-6)
+    np.testing.assert_allclose(loss, float(z["loss"]), rtol=1e-5)
+    np.testing.assert_allclose(grad.numpy(), z["grad"], atol=1e-6)
+    np.testing.assert_allclose(after.numpy(), z["param_after"], atol=1e-6)
+
+
+def test_a3_single_vector(golden):
+    z = golden("a3_single")
+    qs, ps = R.single_vector_case()
+    np.testing.assert_allclose(O.dot_single_vector(qs, ps).numpy(), z["scores"], atol=1e-5)
+    with pytest.raises(ValueError):
+        O.dot_single_vector([], ps)
+    with pytest.raises(ValueError):
+        O.dot_single_vector(qs, [])
+
+
+def test_a2_unmasked_lists(golden):
+    z = golden("a2_unmasked_lists")
+    qs, ps = R.ragged_lists_case()
+    np.testing.assert_allclose(O.maxsim_unmasked_lists(qs, ps, batch_size=4).numpy(), z["scores_bs4"], atol=2e-6)
+    np.testing.assert_allclose(O.maxsim_unmasked_lists(qs, ps, batch_size=128).numpy(), z["scores_bs128"], atol=2e-6)
+    # the zero-pad quirk: batch composition changes scores (padding rows join the max)
+    assert not np.allclose(z["scores_bs4"], z["scores_bs128"])
+
+
+def test_metrics_closed_form():
+    """PARITY UNPINNED vs mteb; single-relevant closed form: nDCG@k = 1/log2(1+rank) if rank<=k."""
+    import math
+    qrels = {"q0": {"d3": 1}, "q1": {"d0": 1}, "q2": {"d9": 1}}
+    results = {
+        "q0": {f"d{i}": float(10 - i) for i in range(10)},            # d3 at rank 4
+        "q1": {f"d{i}": float(10 - i) for i in range(10)},            # d0 at rank 1
+        "q2": {f"d{i}": float(10 - i) for i in range(10)},            # d9 at rank 10
+    }
+    m = O.trec_metrics(qrels, results, [1, 3, 5, 10])
+    assert m["NDCG"]["NDCG@5"] == round((1 / math.log2(5) + 1.0 + 0.0) / 3, 5)
+    assert m["Recall"]["Recall@1"] == round(1 / 3, 5)
+    assert m["NDCG"]["NDCG@10"] == round((1 / math.log2(5) + 1.0 + 1 / math.log2(11)) / 3, 5)
+    assert m["mRR"]["MRR@10"] == round((1 / 4 + 1 + 1 / 10) / 3, 5)
+    assert m["Precision"]["P@5"] == round((1 / 5 + 1 / 5 + 0) / 3, 5)
+    assert m["mAP"]["MAP@5"] == round((1 / 4 + 1 + 0) / 3, 5)
