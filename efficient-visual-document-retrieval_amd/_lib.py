@@ -1,0 +1,75 @@
+"""ctypes binding of the C-ABI library (include/evdr.h).  No fallback of any kind: if libevdr.so is
+missing or a call fails, an exception is raised -- the GPU path is the only product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libevdr.so")
+
+EVDR_OK, EVDR_ERR_ARG, EVDR_ERR_SHAPE, EVDR_ERR_WORKSPACE, EVDR_ERR_HIP = 0, 1, 2, 3, 4
+EVDR_F32, EVDR_BF16 = 0, 1
+EVDR_TOPK_MAX = 128
+
+_i64, _i32, _f32, _sz, _vp = C.c_int64, C.c_int32, C.c_float, C.c_size_t, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/evdr.h one to one (tests check the export list against the header)
+SIGNATURES = {
+    "evdr_version": (C.c_int, []),
+    "evdr_last_error": (C.c_char_p, []),
+    "evdr_pack_pmask": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "evdr_split_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "evdr_maxsim_fwd_workspace": (_sz, [_i64, _i64, _i64, _i64, C.c_int]),
+    "evdr_maxsim_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
+    "evdr_maxsim_fwd_prepared": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64, _vp]),
+    "evdr_maxsim_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "evdr_topk": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, C.c_int, _vp, _vp, _vp]),
+    "evdr_maxsim_topk_workspace": (_sz, [_i64, _i64]),
+    "evdr_maxsim_topk": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64, _i32, C.c_int, _vp, _vp, _vp, _sz, _vp]),
+    "evdr_infonce_distill_fwd_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
+}
+
+
+class EvdrError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libevdr status {code}: {msg}")
+        self.code = code
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libevdr.so (built by `evdr_amd.build.build()`); raises if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import "
+            f"__graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback for this path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != EVDR_OK:
+        msg = load().evdr_last_error()
+        raise EvdrError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_handle(device) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

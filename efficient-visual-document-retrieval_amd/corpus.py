@@ -1,0 +1,155 @@
+"""Resident page corpus, per-shard top-k and the multi-GPU merge (SURVEY §8(d),(e); BASELINE.json config 4).
+
+None of this exists in the reference (single process, whole corpus on one device, ranking on the host from a
+dict of every score).  MI355X layout: the corpus is stored page-major in HBM as bf16 planes (1 plane = a bf16
+corpus, 3 planes = an fp32 corpus split hi/mid/lo), 263 680 B per 1030-patch page and plane, plus 4 B per
+32-patch tile of packed mask; it is prepared once and stays resident (100 k pages = 26.4 GB of 288 GB).
+Pages shard contiguously over ranks; queries are replicated; each rank scores its shard and keeps k
+candidates per query; ONE all-gather of (nq, 2k) int32 words per rank (scores bit-cast next to global page
+indices: 0.8 MB per rank at nq = 1024, k = 100) moves them; every rank merges with the same top-k kernel.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+def shard_range(n_pages: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of rank `rank`: ceil-sized shards, the last ones may be short or empty."""
+    per = (n_pages + world - 1) // world
+    lo = min(rank * per, n_pages)
+    return lo, min(lo + per, n_pages)
+
+
+class PageCorpus:
+    """One rank's prepared, HBM-resident slice of the page corpus."""
+
+    def __init__(self, planes: torch.Tensor, tilemask: torch.Tensor, pageflags: torch.Tensor, idx_base: int = 0):
+        if planes.dim() != 4 or planes.dtype != torch.bfloat16 or planes.shape[0] not in (1, 3) or planes.shape[-1] != ops.D:
+            raise RuntimeError("planes must be (1|3, np, lp, 128) bf16")
+        self.planes = planes.contiguous()
+        self.tilemask = tilemask
+        self.pageflags = pageflags
+        self.idx_base = int(idx_base)
+        self.nplanes, self.n_pages, self.lp, _ = planes.shape
+        self.device = planes.device
+
+    @classmethod
+    def from_tensor(cls, P: torch.Tensor, pmask: Optional[torch.Tensor] = None, idx_base: int = 0) -> "PageCorpus":
+        """P (np, lp, 128): bf16 is kept as one plane, anything else is treated as fp32 and split into 3."""
+        dev = ops._require_cuda(P)
+        npg, lp, _ = P.shape
+        planes = P.contiguous()[None] if P.dtype == torch.bfloat16 else ops.split_f32(P)
+        tilemask, pageflags = ops.pack_pmask(pmask, npg, lp, dev)
+        return cls(planes, tilemask, pageflags, idx_base)
+
+    def _query_planes(self, Q: torch.Tensor) -> torch.Tensor:
+        if self.nplanes == 1:
+            if Q.dtype != torch.bfloat16:
+                raise RuntimeError("bf16 corpus needs bf16 queries (round them explicitly with .bfloat16(), or "
+                                   "build the corpus from fp32 to score at fp32 accuracy)")
+            return Q.contiguous()[None]
+        return ops.split_f32(Q)
+
+    def score(self, Q: torch.Tensor, qmask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              out_col: int = 0) -> torch.Tensor:
+        """(nq, n_pages) fp32 scores of this shard; with `out` given, written into out[:, out_col:out_col+n_pages]."""
+        dev = ops._require_cuda(Q)
+        nq, lq, _ = Q.shape
+        if out is None:
+            out = torch.empty((nq, self.n_pages), dtype=torch.float32, device=dev)
+            out_col = 0
+        view = out[:, out_col:out_col + self.n_pages]
+        if nq == 0 or self.n_pages == 0:
+            return view
+        qp = self._query_planes(Q)
+        qm = ops._mask_u8(qmask, (nq, lq), dev)
+        lib = L.load()
+        with torch.cuda.device(dev):
+            L.check(lib.evdr_maxsim_fwd_prepared(
+                L.ptr(qp), L.ptr(self.planes), L.ptr(qm), L.ptr(self.tilemask), L.ptr(self.pageflags),
+                view.data_ptr(), out.stride(0), None, nq, lq, self.n_pages, self.lp, self.nplanes,
+                self.lp * ops.D, self.n_pages * self.lp * ops.D, L.current_stream_handle(dev)))
+        return view
+
+    def topk(self, Q: torch.Tensor, qmask: Optional[torch.Tensor], k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Per-query top-k of this shard with GLOBAL page indices (idx_base added): (nq,k) fp32, (nq,k) int32."""
+        dev = ops._require_cuda(Q)
+        nq, lq, _ = Q.shape
+        ts = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        ti = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        if nq == 0:
+            return ts, ti
+        if self.n_pages == 0:
+            ts.fill_(float("-inf"))
+            ti.fill_(-1)
+            return ts, ti
+        qp = self._query_planes(Q)
+        qm = ops._mask_u8(qmask, (nq, lq), dev)
+        lib = L.load()
+        ws = ops.workspace(lib.evdr_maxsim_topk_workspace(nq, self.n_pages), dev)
+        with torch.cuda.device(dev):
+            L.check(lib.evdr_maxsim_topk(
+                L.ptr(qp), L.ptr(self.planes), L.ptr(qm), L.ptr(self.tilemask), L.ptr(self.pageflags),
+                nq, lq, self.n_pages, self.lp, self.nplanes, self.lp * ops.D, self.n_pages * self.lp * ops.D,
+                self.idx_base, k, L.ptr(ts), L.ptr(ti), L.ptr(ws), ws.numel(), L.current_stream_handle(dev)))
+        return ts, ti
+
+
+# ---- candidate exchange ---------------------------------------------------------------------------
+def pack_candidates(scores: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """(nq,k) fp32 + (nq,k) int32 -> one (nq, 2k) int32 message (scores bit-cast), so one collective moves both."""
+    return torch.cat([scores.contiguous().view(torch.int32), idx.to(torch.int32)], dim=1).contiguous()
+
+
+def unpack_candidates(buf: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(world, nq, 2k) int32 -> rank-major candidate lists (nq, world*k) scores fp32 and global indices int32."""
+    world, nq, two_k = buf.shape
+    k = two_k // 2
+    sc = buf[:, :, :k].contiguous().view(torch.float32).permute(1, 0, 2).reshape(nq, world * k)
+    ix = buf[:, :, k:].permute(1, 0, 2).reshape(nq, world * k)
+    return sc.contiguous(), ix.contiguous()
+
+
+def gather_candidates(scores: torch.Tensor, idx: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All-gather every rank's (nq,k) candidates.  backend nccl (= RCCL over xGMI): device tensors go straight
+    into ncclAllGather; backend gloo (CPU rehearsal): staged through host memory."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    msg = pack_candidates(scores, idx)
+    backend = dist.get_backend(group)
+    if backend == "gloo" and msg.is_cuda:
+        host = msg.cpu()
+        buf = torch.empty((world * host.shape[0], host.shape[1]), dtype=torch.int32)
+        dist.all_gather_into_tensor(buf, host, group=group)
+        buf = buf.to(msg.device)
+    else:
+        # output = the ranks' messages concatenated along dim 0 (the layout both RCCL and gloo accept)
+        buf = torch.empty((world * msg.shape[0], msg.shape[1]), dtype=torch.int32, device=msg.device)
+        dist.all_gather_into_tensor(buf, msg, group=group)
+    return unpack_candidates(buf.view(world, msg.shape[0], msg.shape[1]))
+
+
+def merge_candidates(scores: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rank-major candidate lists -> final top-k (score desc, global index asc) with the HIP top-k kernel."""
+    return ops.topk(scores, k, idx_map=idx)
+
+
+class ShardedRetriever:
+    """Late-interaction retrieval over a page-sharded corpus: local MaxSim + top-k, one all-gather, merge."""
+
+    def __init__(self, shard: PageCorpus, group=None):
+        self.shard = shard
+        self.group = group
+
+    def search(self, Q: torch.Tensor, qmask: Optional[torch.Tensor], k: int = 100) -> Tuple[torch.Tensor, torch.Tensor]:
+        import torch.distributed as dist
+        ls, li = self.shard.topk(Q, qmask, k)
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return ls, li
+        sc, ix = gather_candidates(ls, li, self.group)
+        return merge_candidates(sc, ix, k)

@@ -1,0 +1,220 @@
+// C-ABI entry points (include/evdr.h).  Argument checking + workspace carving + kernel dispatch.
+// Nothing here allocates, frees or synchronises (graph-capture safe); errors come back as status codes.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "evdr_common.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(EVDR_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+inline int64_t ntiles_of(int64_t lp) { return (lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES; }
+
+struct FwdWorkspace {
+    size_t tilemask_off, pageflags_off, qplanes_off, pplanes_off, total;
+};
+
+FwdWorkspace carve_fwd(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype) {
+    FwdWorkspace w{};
+    size_t off = 0;
+    w.tilemask_off = off;
+    off = align_up(off + (size_t)np * ntiles_of(lp) * 4);
+    w.pageflags_off = off;
+    off = align_up(off + (size_t)np * 4);
+    w.qplanes_off = off;
+    if (dtype == EVDR_F32) off = align_up(off + (size_t)3 * nq * lq * EVDR_D * 2);
+    w.pplanes_off = off;
+    if (dtype == EVDR_F32) off = align_up(off + (size_t)3 * np * lp * EVDR_D * 2);
+    w.total = off;
+    return w;
+}
+
+int check_common(int64_t nq, int64_t lq, int64_t np, int64_t lp) {
+    if (nq < 0 || lq < 0 || np < 0 || lp < 0) return fail(EVDR_ERR_ARG, "negative size");
+    if (nq > INT32_MAX || np > INT32_MAX || lq > 65535 || lp > 65535)
+        return fail(EVDR_ERR_SHAPE, "size out of range (nq=%lld lq=%lld np=%lld lp=%lld)", (long long)nq,
+                    (long long)lq, (long long)np, (long long)lp);
+    return EVDR_OK;
+}
+
+// Runs the forward over 32-token slices of the queries (one slice for Lq <= 32).
+int run_fwd(const uint16_t* Qp, int64_t q_stride, int64_t q_plane_stride, const uint16_t* Pp, int64_t p_stride,
+            int64_t p_plane_stride, const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
+            float* out, int64_t out_stride, uint16_t* argmax, int64_t nq, int64_t lq, int64_t np, int64_t lp,
+            int nplanes, hipStream_t stream) {
+    for (int64_t tok0 = 0; tok0 < lq; tok0 += 32) {
+        EvdrFwdParams p{};
+        p.Q = Qp;
+        p.q_stride = q_stride;
+        p.q_plane_stride = q_plane_stride;
+        p.P = Pp;
+        p.p_stride = p_stride;
+        p.p_plane_stride = p_plane_stride;
+        p.qmask = qmask;
+        p.tilemask = tilemask;
+        p.pageflags = pageflags;
+        p.out = out;
+        p.out_stride = out_stride;
+        p.argmax = argmax;
+        p.nq = (int)nq;
+        p.lq = (int)((lq - tok0 < 32) ? (lq - tok0) : 32);
+        p.np = (int)np;
+        p.lp = (int)lp;
+        p.tok0 = (int)tok0;
+        p.lq_total = (int)lq;
+        p.accumulate = tok0 > 0 ? 1 : 0;
+        hipError_t e = evdr_launch_maxsim_fwd(p, nplanes, argmax != nullptr, stream);
+        if (e != hipSuccess) return hip_fail(e, "maxsim_fwd launch");
+    }
+    return EVDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int evdr_version(void) { return EVDR_VERSION_NUM; }
+
+const char* evdr_last_error(void) { return g_err; }
+
+int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, uint32_t* tilemask, uint32_t* pageflags,
+                    void* hip_stream) {
+    if (int rc = check_common(0, 0, np, lp)) return rc;
+    if (!tilemask || !pageflags) return fail(EVDR_ERR_ARG, "evdr_pack_pmask: null output");
+    if (np == 0) return EVDR_OK;
+    if (lp == 0) return fail(EVDR_ERR_SHAPE, "evdr_pack_pmask: lp == 0");
+    hipError_t e = evdr_launch_pack_pmask(pmask, np, lp, tilemask, pageflags, (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "pack_pmask launch");
+}
+
+int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, void* hip_stream) {
+    if (rows < 0) return fail(EVDR_ERR_ARG, "evdr_split_f32: negative rows");
+    if (rows == 0) return EVDR_OK;
+    if (!x || !planes) return fail(EVDR_ERR_ARG, "evdr_split_f32: null pointer");
+    hipError_t e = evdr_launch_split_f32(x, rows, planes, (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "split_f32 launch");
+}
+
+size_t evdr_maxsim_fwd_workspace(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype) {
+    if (nq < 0 || lq < 0 || np < 0 || lp < 0) return 0;
+    return carve_fwd(nq, lq, np, lp, dtype).total;
+}
+
+int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const uint8_t* pmask, float* out,
+                    uint16_t* argmax_or_null, int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d, int dtype,
+                    const int64_t* strides_or_null, void* workspace, size_t workspace_bytes, void* hip_stream) {
+    if (int rc = check_common(nq, lq, np, lp)) return rc;
+    if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported (kernels are built for 128)", (long long)d);
+    if (dtype != EVDR_F32 && dtype != EVDR_BF16) return fail(EVDR_ERR_ARG, "dtype must be EVDR_F32 or EVDR_BF16");
+    if (nq == 0 || np == 0) return EVDR_OK;                      // empty score matrix
+    if (lq == 0 || lp == 0) return fail(EVDR_ERR_SHAPE, "zero-length token axis (lq=%lld lp=%lld)", (long long)lq, (long long)lp);
+    if (!Q || !P || !out) return fail(EVDR_ERR_ARG, "evdr_maxsim_fwd: null Q/P/out");
+    const int64_t q_stride = strides_or_null ? strides_or_null[0] : lq * EVDR_D;
+    const int64_t p_stride = strides_or_null ? strides_or_null[1] : lp * EVDR_D;
+    if (q_stride < lq * EVDR_D || p_stride < lp * EVDR_D) return fail(EVDR_ERR_ARG, "strides smaller than a row block");
+    const FwdWorkspace w = carve_fwd(nq, lq, np, lp, dtype);
+    if (!workspace || workspace_bytes < w.total)
+        return fail(EVDR_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.total, workspace_bytes);
+    hipStream_t stream = (hipStream_t)hip_stream;
+    char* ws = (char*)workspace;
+    uint32_t* tilemask = (uint32_t*)(ws + w.tilemask_off);
+    uint32_t* pageflags = (uint32_t*)(ws + w.pageflags_off);
+    hipError_t e = evdr_launch_pack_pmask(pmask, np, lp, tilemask, pageflags, stream);
+    if (e != hipSuccess) return hip_fail(e, "pack_pmask launch");
+    if (dtype == EVDR_BF16) {
+        return run_fwd((const uint16_t*)Q, q_stride, 0, (const uint16_t*)P, p_stride, 0, qmask, tilemask, pageflags, out,
+                       np, argmax_or_null, nq, lq, np, lp, 1, stream);
+    }
+    if (q_stride != lq * EVDR_D || p_stride != lp * EVDR_D)
+        return fail(EVDR_ERR_ARG, "fp32 inputs must be dense (make them contiguous before the call)");
+    uint16_t* qpl = (uint16_t*)(ws + w.qplanes_off);
+    uint16_t* ppl = (uint16_t*)(ws + w.pplanes_off);
+    if ((e = evdr_launch_split_f32((const float*)Q, nq * lq, qpl, stream)) != hipSuccess) return hip_fail(e, "split Q");
+    if ((e = evdr_launch_split_f32((const float*)P, np * lp, ppl, stream)) != hipSuccess) return hip_fail(e, "split P");
+    return run_fwd(qpl, lq * EVDR_D, nq * lq * EVDR_D, ppl, lp * EVDR_D, np * lp * EVDR_D, qmask, tilemask, pageflags, out,
+                   np, argmax_or_null, nq, lq, np, lp, 3, stream);
+}
+
+int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes, const uint8_t* qmask,
+                             const uint32_t* tilemask, const uint32_t* pageflags, float* out, int64_t out_stride,
+                             uint16_t* argmax_or_null, int64_t nq, int64_t lq, int64_t np, int64_t lp, int nplanes,
+                             int64_t p_stride, int64_t p_plane_stride, void* hip_stream) {
+    if (int rc = check_common(nq, lq, np, lp)) return rc;
+    if (nplanes != 1 && nplanes != 3) return fail(EVDR_ERR_ARG, "nplanes must be 1 or 3");
+    if (nq == 0 || np == 0) return EVDR_OK;
+    if (lq == 0 || lp == 0) return fail(EVDR_ERR_SHAPE, "zero-length token axis");
+    if (!Qplanes || !Pplanes || !tilemask || !pageflags || !out) return fail(EVDR_ERR_ARG, "evdr_maxsim_fwd_prepared: null pointer");
+    if (out_stride < np || p_stride < lp * EVDR_D) return fail(EVDR_ERR_ARG, "stride smaller than the row it spans");
+    return run_fwd(Qplanes, lq * EVDR_D, nq * lq * EVDR_D, Pplanes, p_stride, p_plane_stride, qmask, tilemask, pageflags, out,
+                   out_stride, argmax_or_null, nq, lq, np, lp, nplanes, (hipStream_t)hip_stream);
+}
+
+int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
+                    float* dP, int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d, void* hip_stream) {
+    if (int rc = check_common(nq, lq, np, lp)) return rc;
+    if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported", (long long)d);
+    if (np == 0 || lp == 0) return EVDR_OK;
+    if (!dP) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd: null dP");
+    if (nq > 0 && lq > 0 && (!g || !Q || !argmax)) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd: null g/Q/argmax");
+    hipError_t e = evdr_launch_maxsim_bwd(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd launch");
+}
+
+int evdr_topk(const float* scores, const int32_t* idx_map_or_null, int64_t nq, int64_t n, int64_t row_stride,
+              int32_t idx_base, int k, float* top_scores, int32_t* top_idx, void* hip_stream) {
+    if (nq < 0 || n < 0) return fail(EVDR_ERR_ARG, "negative size");
+    if (k < 1 || k > EVDR_TOPK_MAX) return fail(EVDR_ERR_ARG, "k=%d outside 1..%d", k, EVDR_TOPK_MAX);
+    if (nq == 0) return EVDR_OK;
+    if (!top_scores || !top_idx || (n > 0 && !scores)) return fail(EVDR_ERR_ARG, "evdr_topk: null pointer");
+    if (row_stride < n) return fail(EVDR_ERR_ARG, "row_stride < n");
+    hipError_t e = evdr_launch_topk(scores, idx_map_or_null, nq, n, row_stride, idx_base, k, top_scores, top_idx,
+                                    (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "topk launch");
+}
+
+size_t evdr_maxsim_topk_workspace(int64_t nq, int64_t np) {
+    if (nq < 0 || np < 0) return 0;
+    return align_up((size_t)nq * np * sizeof(float));
+}
+
+int evdr_maxsim_topk(const uint16_t* Qplanes, const uint16_t* Pplanes, const uint8_t* qmask, const uint32_t* tilemask,
+                     const uint32_t* pageflags, int64_t nq, int64_t lq, int64_t np, int64_t lp, int nplanes,
+                     int64_t p_stride, int64_t p_plane_stride, int32_t idx_base, int k, float* top_scores,
+                     int32_t* top_idx, void* workspace, size_t workspace_bytes, void* hip_stream) {
+    if (!workspace || workspace_bytes < evdr_maxsim_topk_workspace(nq, np))
+        return fail(EVDR_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu",
+                    evdr_maxsim_topk_workspace(nq, np), workspace_bytes);
+    float* scores = (float*)workspace;
+    int rc = evdr_maxsim_fwd_prepared(Qplanes, Pplanes, qmask, tilemask, pageflags, scores, np, nullptr, nq, lq, np, lp,
+                                      nplanes, p_stride, p_plane_stride, hip_stream);
+    if (rc != EVDR_OK) return rc;
+    return evdr_topk(scores, nullptr, nq, np, np, idx_base, k, top_scores, top_idx, hip_stream);
+}
+
+int evdr_infonce_distill_fwd_bwd(const float* score_s, const float* score_t, int64_t b, int64_t n, float temperature,
+                                 float* loss, float* dscore_or_null, float* row_loss, void* hip_stream) {
+    if (b < 0 || n < 0) return fail(EVDR_ERR_ARG, "negative size");
+    if (!(temperature > 0.f)) return fail(EVDR_ERR_ARG, "temperature must be > 0");
+    if (b == 0 || n == 0) return fail(EVDR_ERR_SHAPE, "empty score matrix (b=%lld n=%lld)", (long long)b, (long long)n);
+    if (!score_s || !score_t || !loss || !row_loss) return fail(EVDR_ERR_ARG, "evdr_infonce_distill_fwd_bwd: null pointer");
+    hipError_t e = evdr_launch_infonce(score_s, score_t, b, n, temperature, loss, dscore_or_null, row_loss,
+                                       (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "infonce launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// Shared declarations for the gfx950 kernels and the C-ABI dispatch (include/evdr.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/evdr.h"
+
+#define EVDR_VERSION_NUM 100   /* 0.1.0 */
+
+#define EVDR_D 128              /* embedding width the kernels are specialised for */
+#define EVDR_TILE_PATCHES 32    /* patches per MFMA tile (mfma_f32_32x32x16_bf16 rows) */
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- forward --------------------------------------------------------------------------------
+struct EvdrFwdParams {
+    const uint16_t* Q;          // bf16 planes; query q, token n at Q + q*q_stride + n*128
+    int64_t q_stride;           // elements between queries
+    int64_t q_plane_stride;     // elements between Q planes
+    const uint16_t* P;          // bf16 planes; page-major (np, lp, 128) per plane
+    int64_t p_stride;           // elements between pages
+    int64_t p_plane_stride;     // elements between P planes
+    const uint8_t* qmask;       // (nq, lq) or null
+    const uint32_t* tilemask;   // (np, ntiles)
+    const uint32_t* pageflags;  // (np)
+    float* out;                 // (nq, out_stride)
+    int64_t out_stride;
+    uint16_t* argmax;           // (nq, np, lq) or null
+    int nq, lq, np, lp, ntiles; // lq = tokens scored by THIS launch (<= 32), starting at token tok0
+    int tok0, lq_total;         // lq_total = row length of qmask / argmax (queries longer than 32 tokens
+    int accumulate;             //   are scored in 32-token slices, later slices add into out)
+    int pages_per_block, n_qgroups, n_chunks;
+};
+
+// launches (defined in the .hip files; all enqueue on `stream` and return the launch status)
+hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& p, int nplanes, bool want_argmax, hipStream_t stream);
+hipError_t evdr_launch_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, uint32_t* tilemask,
+                                  uint32_t* pageflags, hipStream_t stream);
+hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes, hipStream_t stream);
+hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
+                                  const uint16_t* argmax, float* dP, int64_t nq, int64_t lq, int64_t np,
+                                  int64_t lp, hipStream_t stream);
+hipError_t evdr_launch_topk(const float* scores, const int32_t* idx_map, int64_t nq, int64_t n,
+                            int64_t row_stride, int32_t idx_base, int k, float* top_scores, int32_t* top_idx,
+                            hipStream_t stream);
+hipError_t evdr_launch_infonce(const float* ss, const float* st, int64_t b, int64_t n, float temperature,
+                               float* loss, float* dscore, float* row_loss, hipStream_t stream);

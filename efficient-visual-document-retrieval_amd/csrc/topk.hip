@@ -1,0 +1,151 @@
+// Per-query top-k over a (nq, n) fp32 score matrix, entirely on device.  Replaces the reference's
+// Nq*N `.item()` loop that moves every score to the host before ranking
+// (mainv2_iter_distill_infonce.py:311-317); k = 100 covers every cut-off in evaluator/retrieval.py:223.
+//
+// One 256-thread workgroup per row: 4 x 8-bit radix-select passes find the k-th largest key exactly,
+// one pass gathers the candidates, a 128-wide bitonic sort orders them.  Order is total and
+// deterministic: score descending, reported index ascending on ties (the shard merge relies on it).
+// HBM-bound integer work: the row is read once from HBM, the re-reads hit L2 (400 KB per 100k-page row).
+#include "evdr_common.h"
+
+namespace {
+
+constexpr int TK_THREADS = 256;
+
+__device__ __forceinline__ uint32_t order_key(float f) {
+    f = f + 0.0f;                                    // -0.0 -> +0.0 so that equal scores tie
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __builtin_bit_cast(float, u);
+}
+
+__global__ void __launch_bounds__(TK_THREADS) topk_kernel(const float* __restrict__ scores,
+                                                         const int32_t* __restrict__ idx_map, int64_t n,
+                                                         int64_t row_stride, int32_t idx_base, int k,
+                                                         float* __restrict__ top_scores,
+                                                         int32_t* __restrict__ top_idx) {
+    __shared__ uint32_t hist[TK_THREADS];
+    __shared__ uint32_t suf[TK_THREADS + 1];
+    __shared__ unsigned long long cand[EVDR_TOPK_MAX];
+    __shared__ uint32_t sh_prefix, sh_need, sh_cnt_eq, sh_cnt_gt_slot, sh_eq_slot, sh_wave_tot[TK_THREADS / 64];
+    __shared__ uint32_t sh_eq_base;
+
+    const int tid = threadIdx.x;
+    const int64_t rowi = blockIdx.x;
+    const float* row = scores + rowi * row_stride;
+    const int32_t* map = idx_map ? idx_map + rowi * n : nullptr;
+    const int keff = (int)min((int64_t)k, n);
+
+    if (tid < EVDR_TOPK_MAX) cand[tid] = 0ull;       // key 0 sorts below every real score
+    if (tid == 0) { sh_prefix = 0; sh_need = (uint32_t)keff; sh_cnt_gt_slot = 0; sh_eq_slot = 0; sh_eq_base = 0; }
+    __syncthreads();
+
+    if (keff > 0) {
+        // ---- radix select, most significant byte first
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = sh_prefix;
+            const uint32_t himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int64_t i = tid; i < n; i += TK_THREADS) {
+                const uint32_t key = order_key(row[i]);
+                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            // suffix sums: suf[t] = sum_{b >= t} hist[b]
+            suf[tid] = hist[tid];
+            if (tid == 0) suf[TK_THREADS] = 0;
+            __syncthreads();
+            for (int off = 1; off < TK_THREADS; off <<= 1) {
+                uint32_t add = (tid + off < TK_THREADS) ? suf[tid + off] : 0u;
+                __syncthreads();
+                suf[tid] += add;
+                __syncthreads();
+            }
+            const uint32_t need = sh_need;
+            if (suf[tid] >= need && suf[tid + 1] < need) {      // exactly one thread
+                sh_prefix = prefix | ((uint32_t)tid << shift);
+                sh_need = need - suf[tid + 1];
+                sh_cnt_eq = hist[tid];
+            }
+            __syncthreads();
+        }
+        const uint32_t T = sh_prefix;             // key of the k-th largest element
+        const uint32_t need_eq = sh_need;         // how many elements == T belong to the top-k
+        const uint32_t n_gt = (uint32_t)keff - need_eq;
+        const bool take_all_eq = (sh_cnt_eq == need_eq);
+
+        // ---- gather: everything above T, plus (all | the first need_eq in index order) of == T
+        for (int64_t i = tid; i < n; i += TK_THREADS) {
+            const uint32_t key = order_key(row[i]);
+            const bool gt = key > T;
+            const bool eq = take_all_eq && key == T;
+            if (gt || eq) {
+                const uint32_t slot = gt ? atomicAdd(&sh_cnt_gt_slot, 1u) : n_gt + atomicAdd(&sh_eq_slot, 1u);
+                const uint32_t rep = (uint32_t)(map ? map[i] : (int32_t)i + idx_base);
+                cand[slot] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - rep);
+            }
+        }
+        if (!take_all_eq) {
+            // the tie straddles the cut: ordered scan, stop once need_eq have been taken
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int64_t base = 0; base < n; base += TK_THREADS) {
+                const int64_t i = base + tid;
+                const bool eq = (i < n) && order_key(row[i]) == T;
+                const unsigned long long bal = __ballot(eq);
+                if (lane == 0) sh_wave_tot[wv] = (uint32_t)__popcll(bal);
+                __syncthreads();
+                uint32_t before = sh_eq_base;
+                for (int w = 0; w < wv; ++w) before += sh_wave_tot[w];
+                const uint32_t rank = before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (eq && rank < need_eq) {
+                    const uint32_t rep = (uint32_t)(map ? map[i] : (int32_t)i + idx_base);
+                    cand[n_gt + rank] = ((unsigned long long)T << 32) | (0xFFFFFFFFu - rep);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t tot = 0;
+                    for (int w = 0; w < TK_THREADS / 64; ++w) tot += sh_wave_tot[w];
+                    sh_eq_base += tot;
+                }
+                __syncthreads();
+                if (sh_eq_base >= need_eq) break;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- bitonic sort, descending, 128 slots (unused slots hold 0 and sink to the end)
+    for (int size = 2; size <= EVDR_TOPK_MAX; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (tid < EVDR_TOPK_MAX / 2) {
+                const int lo = 2 * tid - (tid & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = cand[lo], b = cand[hi];
+                if ((a < b) == desc) { cand[lo] = b; cand[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < k) {
+        const unsigned long long c = cand[tid];
+        const bool real = tid < keff;
+        top_scores[rowi * k + tid] = real ? key_to_float((uint32_t)(c >> 32)) : -__builtin_inff();
+        top_idx[rowi * k + tid] = real ? (int32_t)(0xFFFFFFFFu - (uint32_t)c) : -1;
+    }
+}
+
+}  // namespace
+
+hipError_t evdr_launch_topk(const float* scores, const int32_t* idx_map, int64_t nq, int64_t n, int64_t row_stride,
+                            int32_t idx_base, int k, float* top_scores, int32_t* top_idx, hipStream_t stream) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)nq), dim3(TK_THREADS), 0, stream, scores, idx_map, n, row_stride,
+                       idx_base, k, top_scores, top_idx);
+    return hipGetLastError();
+}

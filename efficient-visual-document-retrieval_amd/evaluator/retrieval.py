@@ -1,0 +1,173 @@
+"""Drop-in counterpart of the reference's `evaluator/retrieval.py` for the MaxSim hot path.
+
+Same public names, argument meaning, return types and error behaviour as the reference module, so that
+`from evaluator.retrieval import score_multi_vector_masked, CustomRetrievalEvaluator`
+(mainv2_iter_distill_infonce.py:20 and the 20 sibling scripts) keeps working when this module is put in its
+place.  The arithmetic runs in hand-written gfx950 kernels behind the C ABI of
+include/evdr.h; there is no torch/CPU fallback for the multi-vector scorers.
+
+Reference lines mirrored:
+  get_torch_device                      evaluator/retrieval.py:10-28
+  BaseVisualRetrieverProcessor          :47-164  (score_single_vector :78-99, score_multi_vector :101-150)
+  score_multi_vector_masked             :166-213
+  CustomRetrievalEvaluator              :220-255
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Dict, List, Optional, Tuple, Union
+
+import torch
+
+from .. import ops
+from . import metrics as _metrics
+
+__all__ = ["get_torch_device", "BaseVisualRetrieverProcessor", "score_multi_vector_masked",
+           "CustomRetrievalEvaluator"]
+
+
+def get_torch_device(device: str = "auto") -> str:
+    """"auto" -> "cuda:0" when a GPU is visible (ROCm exposes MI355X as cuda), else "cpu"."""
+    if device == "auto":
+        return "cuda:0" if torch.cuda.is_available() else "cpu"
+    return device
+
+
+# ------------------------------------------------------------------------------------------------
+# A1 + A6: masked MaxSim, differentiable w.r.t. the page embeddings
+# ------------------------------------------------------------------------------------------------
+class _MaxSimMasked(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Q, P, qmask, pmask):
+        need_dp = ctx.needs_input_grad[1]
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError(
+                "gradient w.r.t. the query embeddings is not implemented (no reference script trains Q); "
+                "detach Q or open an issue")
+        out, arg = ops.maxsim_forward(Q, P, qmask, pmask, want_argmax=need_dp)
+        if need_dp:
+            ctx.save_for_backward(Q.detach(), qmask, pmask, arg)
+            ctx.p_shape = tuple(P.shape)
+            ctx.p_dtype = P.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Q, qmask, pmask, arg = ctx.saved_tensors
+        npg, lp, _ = ctx.p_shape
+        dP = ops.maxsim_backward(g, Q, qmask, pmask, arg, npg, lp)
+        return None, dP.to(ctx.p_dtype), None, None
+
+
+def score_multi_vector_masked(
+    Q: torch.Tensor,        # (Nq, Lq, D)
+    P: torch.Tensor,        # (Np, Lp, D)
+    qmask: torch.Tensor,    # (Nq, Lq) bool-like
+    pmask: torch.Tensor,    # (Np, Lp) bool-like
+    chunk_p: int = 128,
+) -> torch.Tensor:
+    """out[q,p] = sum_n qmask[q,n] * any(pmask[p]) * max_m(Q[q,n]·P[p,m] if pmask[p,m] else -1e4), fp32,
+    on the inputs' device, autograd-capable w.r.t. P.  `chunk_p` only bounded the reference's 4-D
+    intermediate (evaluator/retrieval.py:187); the fused kernel has none, so it is accepted and ignored."""
+    del chunk_p
+    return _MaxSimMasked.apply(Q, P, qmask, pmask)
+
+
+# ------------------------------------------------------------------------------------------------
+# A2 / A3: the ColPali-style list scorers
+# ------------------------------------------------------------------------------------------------
+def _left_pad_stack(seqs: List[torch.Tensor], device) -> torch.Tensor:
+    """Zero LEFT padding to the batch's own max length (evaluator/retrieval.py:30-45), built in one
+    device tensor instead of per-sequence torch.cat."""
+    seqs = [s.unsqueeze(0) if s.ndim == 1 else s for s in seqs]
+    lmax = max(int(s.shape[0]) for s in seqs)
+    d = int(seqs[0].shape[-1])
+    out = torch.zeros((len(seqs), lmax, d), dtype=seqs[0].dtype, device=device)
+    for i, s in enumerate(seqs):
+        if s.shape[0]:
+            out[i, lmax - s.shape[0]:] = s.to(device)
+    return out
+
+
+class BaseVisualRetrieverProcessor(ABC):
+    """Base class for visual retriever processors (same abstract surface as the reference)."""
+
+    @abstractmethod
+    def process_images(self, images):
+        pass
+
+    @abstractmethod
+    def process_queries(self, queries: List[str], max_length: int = 50, suffix: Optional[str] = None):
+        pass
+
+    @abstractmethod
+    def score(self, qs: List[torch.Tensor], ps: List[torch.Tensor],
+              device: Optional[Union[str, torch.device]] = None, **kwargs) -> torch.Tensor:
+        pass
+
+    @staticmethod
+    def score_single_vector(qs: List[torch.Tensor], ps: List[torch.Tensor],
+                            device: Optional[Union[str, torch.device]] = None) -> torch.Tensor:
+        """Dense dot product of pooled vectors -> (Nq, Np) fp32 on `device` (plain torch
+        plumbing, 64 MFLOP at 500x500; runs on CPU or GPU exactly like the reference)."""
+        device = device or get_torch_device("auto")
+        if len(qs) == 0:
+            raise ValueError("No queries provided")
+        if len(ps) == 0:
+            raise ValueError("No passages provided")
+        qv = torch.stack(list(qs)).to(device)
+        pv = torch.stack(list(ps)).to(device)
+        scores = qv @ pv.transpose(0, 1)
+        assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
+        return scores.to(torch.float32)
+
+    @staticmethod
+    def score_multi_vector(qs: Union[torch.Tensor, List[torch.Tensor]], ps: Union[torch.Tensor, List[torch.Tensor]],
+                           batch_size: int = 128, device: Optional[Union[str, torch.device]] = None) -> torch.Tensor:
+        """Unmasked late-interaction scores of ragged lists -> (Nq, Np) fp32 on the CPU.
+
+        Reproduces the reference's batch-composition quirk: each (query batch, page batch) block is
+        zero-left-padded to its own max lengths and the zero page rows TAKE PART in the max
+        (evaluator/retrieval.py:122-136).  With the fused kernel this is simply "no page mask"."""
+        device = device or get_torch_device("auto")
+        if len(qs) == 0:
+            raise ValueError("No queries provided")
+        if len(ps) == 0:
+            raise ValueError("No passages provided")
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("score_multi_vector runs on the GPU (HIP kernels, no CPU fallback); "
+                               f"got device={device!r}")
+        rows = []
+        p_batches = [_left_pad_stack(list(ps[j:j + batch_size]), device) for j in range(0, len(ps), batch_size)]
+        for i in range(0, len(qs), batch_size):
+            qb = _left_pad_stack(list(qs[i:i + batch_size]), device)
+            blocks = []
+            for pb in p_batches:
+                s, _ = ops.maxsim_forward(qb, pb, None, None, want_argmax=False)
+                blocks.append(s)
+            rows.append(torch.cat(blocks, dim=1).cpu())
+        scores = torch.cat(rows, dim=0)
+        assert scores.shape[0] == len(qs), f"Expected {len(qs)} scores, got {scores.shape[0]}"
+        return scores.to(torch.float32)
+
+    @abstractmethod
+    def get_n_patches(self, image_size: Tuple[int, int], patch_size: int = 14, *args, **kwargs) -> Tuple[int, int]:
+        pass
+
+
+# ------------------------------------------------------------------------------------------------
+# A9: metric wrapper
+# ------------------------------------------------------------------------------------------------
+class CustomRetrievalEvaluator:
+    def __init__(self, k_values: List[int] = [1, 3, 5, 10, 50, 70, 100], score_function: str = "cos_sim"):
+        self.k_values = list(k_values)
+        self.score_function = score_function
+
+    def compute_mteb_metrics(self, relevant_docs: Dict[str, Dict[str, int]],
+                             results: Dict[str, Dict[str, float]], **kwargs) -> Dict[str, Dict[str, float]]:
+        """-> {"NDCG": {"NDCG@k"}, "mAP": {"MAP@k"}, "Recall": {"Recall@k"}, "Precision": {"P@k"},
+        "mRR": {"MRR@k"}} like the reference's wrapper over mteb (evaluator/retrieval.py:230-255).
+        `ignore_identical_ids=True` drops result entries whose docid equals the query id, as mteb does."""
+        if kwargs.get("ignore_identical_ids", False):
+            results = {q: {d: s for d, s in ds.items() if d != q} for q, ds in results.items()}
+        return _metrics.evaluate(relevant_docs, results, self.k_values)

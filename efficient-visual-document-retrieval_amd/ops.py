@@ -1,0 +1,170 @@
+"""Thin torch-tensor wrappers over the C ABI (include/evdr.h).  PyTorch is plumbing here: it owns device
+memory and the stream; every computation below runs in libevdr.so's HIP kernels on the caller's current
+stream, with no synchronisation.  CPU tensors are rejected (there is no CPU path in the product)."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+D = 128
+
+
+def _require_cuda(*tensors) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "evdr_amd scores on the GPU only (HIP kernels, no CPU fallback): got a tensor on "
+                f"{t.device}; move inputs to a cuda device")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    if dev is None:
+        raise RuntimeError("no tensors given")
+    return dev
+
+
+def _mask_u8(m: Optional[torch.Tensor], shape, dev) -> Optional[torch.Tensor]:
+    """mask.bool() as the reference does (evaluator/retrieval.py:179-180); one byte per token."""
+    if m is None:
+        return None
+    if tuple(m.shape) != tuple(shape):
+        raise RuntimeError(f"mask shape {tuple(m.shape)} does not match {tuple(shape)}")
+    return m.to(device=dev).bool().contiguous()
+
+
+def workspace(nbytes: int, dev) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+def pack_pmask(pmask: Optional[torch.Tensor], npages: int, lp: int, dev) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(np, lp) byte mask -> (tilemask (np, ceil(lp/32)) int32 bits, pageflags (np,) int32)."""
+    lib = L.load()
+    ntiles = (lp + 31) // 32
+    tilemask = torch.empty((npages, ntiles), dtype=torch.int32, device=dev)
+    pageflags = torch.empty((npages,), dtype=torch.int32, device=dev)
+    pm = _mask_u8(pmask, (npages, lp), dev)
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_pack_pmask(L.ptr(pm), npages, lp, L.ptr(tilemask), L.ptr(pageflags),
+                                    L.current_stream_handle(dev)))
+    return tilemask, pageflags
+
+
+def split_f32(x: torch.Tensor) -> torch.Tensor:
+    """(..., 128) fp32 -> (3, ..., 128) bf16 planes hi/mid/lo with hi+mid+lo == x to ~2^-24."""
+    dev = _require_cuda(x)
+    if x.shape[-1] != D:
+        raise NotImplementedError(f"embedding width {x.shape[-1]} unsupported (kernels are built for {D})")
+    lib = L.load()
+    xc = x.float().contiguous()
+    rows = xc.numel() // D
+    planes = torch.empty((3,) + tuple(xc.shape), dtype=torch.bfloat16, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_split_f32(L.ptr(xc), rows, L.ptr(planes), L.current_stream_handle(dev)))
+    return planes
+
+
+def maxsim_forward(Q: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],
+                   want_argmax: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """A1 (evaluator/retrieval.py:166-213) through evdr_maxsim_fwd.  bf16 x bf16 inputs are scored as
+    they are; anything else is upcast to fp32 like the reference (:176-177) and scored to fp32 accuracy."""
+    dev = _require_cuda(Q, P)
+    if Q.dim() != 3 or P.dim() != 3 or Q.shape[-1] != P.shape[-1]:
+        raise RuntimeError(f"expected Q (Nq,Lq,D) and P (Np,Lp,D), got {tuple(Q.shape)} and {tuple(P.shape)}")
+    nq, lq, d = Q.shape
+    npg, lp, _ = P.shape
+    if d != D:
+        raise NotImplementedError(f"embedding width {d} unsupported (kernels are built for {D})")
+    out = torch.empty((nq, npg), dtype=torch.float32, device=dev)
+    arg = torch.empty((nq, npg, lq), dtype=torch.int16, device=dev) if want_argmax else None
+    if nq == 0 or npg == 0:
+        return out, arg
+    if lq == 0 or lp == 0:
+        raise RuntimeError(f"zero-length token axis (Lq={lq}, Lp={lp})")
+    if lp > 65535 or lq > 65535:
+        raise NotImplementedError("token axes longer than 65535 are not supported")
+    lib = L.load()
+    if Q.dtype == torch.bfloat16 and P.dtype == torch.bfloat16:
+        dtype = L.EVDR_BF16
+        Qc = Q.contiguous()
+        Pc = P if (P.stride(2) == 1 and P.stride(1) == D and P.stride(0) >= lp * D) else P.contiguous()
+    else:
+        dtype = L.EVDR_F32
+        Qc = Q.float().contiguous()
+        Pc = P.float().contiguous()
+    strides = (L.C.c_int64 * 2)(Qc.stride(0), Pc.stride(0))
+    qm = _mask_u8(qmask, (nq, lq), dev)
+    pm = _mask_u8(pmask, (npg, lp), dev)
+    nbytes = lib.evdr_maxsim_fwd_workspace(nq, lq, npg, lp, dtype)
+    ws = workspace(nbytes, dev)
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_maxsim_fwd(L.ptr(Qc), L.ptr(Pc), L.ptr(qm), L.ptr(pm), L.ptr(out), L.ptr(arg),
+                                    nq, lq, npg, lp, d, dtype, strides, L.ptr(ws), ws.numel(),
+                                    L.current_stream_handle(dev)))
+    return out, arg
+
+
+def maxsim_backward(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],
+                    argmax: torch.Tensor, npg: int, lp: int) -> torch.Tensor:
+    """A6: dP (np, lp, 128) fp32 from upstream g (nq, np) and the forward's argmax."""
+    dev = _require_cuda(g, Q, argmax)
+    nq, lq, d = Q.shape
+    lib = L.load()
+    gc = g.float().contiguous()
+    Qc = Q.float().contiguous()
+    qm = _mask_u8(qmask, (nq, lq), dev)
+    pm = _mask_u8(pmask, (npg, lp), dev)
+    dP = torch.empty((npg, lp, d), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_maxsim_bwd(L.ptr(gc), L.ptr(Qc), L.ptr(qm), L.ptr(pm), L.ptr(argmax), L.ptr(dP),
+                                    nq, lq, npg, lp, d, L.current_stream_handle(dev)))
+    return dP
+
+
+def topk(scores: torch.Tensor, k: int, idx_base: int = 0,
+         idx_map: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A8: per-row top-k (score desc, index asc), on device.  scores (nq, n) fp32, row-strided allowed."""
+    dev = _require_cuda(scores)
+    if scores.dim() != 2 or scores.dtype != torch.float32 or scores.stride(1) != 1:
+        raise RuntimeError("scores must be a 2-D fp32 tensor with unit column stride")
+    if not (1 <= k <= L.EVDR_TOPK_MAX):
+        raise ValueError(f"k={k} outside 1..{L.EVDR_TOPK_MAX}")
+    nq, n = scores.shape
+    lib = L.load()
+    ts = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    ti = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    im = None
+    if idx_map is not None:
+        if tuple(idx_map.shape) != (nq, n):
+            raise RuntimeError("idx_map must have the shape of scores")
+        im = idx_map.to(device=dev, dtype=torch.int32).contiguous()
+    row_stride = scores.stride(0) if nq > 1 else max(n, 1)
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_topk(L.ptr(scores), L.ptr(im), nq, n, max(row_stride, n), idx_base, k, L.ptr(ts), L.ptr(ti),
+                              L.current_stream_handle(dev)))
+    return ts, ti
+
+
+def infonce_distill(score_s: torch.Tensor, score_t: torch.Tensor, temperature: float,
+                    want_grad: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """A5 (criterion.py:56-68) + its closed-form gradient in one pass."""
+    dev = _require_cuda(score_s, score_t)
+    if score_s.shape != score_t.shape or score_s.dim() != 2:
+        raise RuntimeError("score_s and score_t must be (B, N) and equal-shaped")
+    b, n = score_s.shape
+    lib = L.load()
+    ss = score_s.float().contiguous()
+    st = score_t.float().contiguous()
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    row = torch.empty((b,), dtype=torch.float32, device=dev)
+    grad = torch.empty_like(ss) if want_grad else None
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_infonce_distill_fwd_bwd(L.ptr(ss), L.ptr(st), b, n, float(temperature), L.ptr(loss),
+                                                 L.ptr(grad), L.ptr(row), L.current_stream_handle(dev)))
+    return loss, grad

@@ -1,0 +1,126 @@
+/*
+ * evdr.h -- C ABI of the MI355X-native late-interaction (MaxSim) scorer.
+ *
+ * The reference (kimjy-st/Efficient-Visual-Document-Retrieval) has no FFI layer: its boundary
+ * for this path is a set of Python function signatures in evaluator/retrieval.py.  Each entry
+ * point below names the reference interface it replaces (paths relative to the reference root).
+ * The Python host shim (efficient-visual-document-retrieval_amd/evaluator/retrieval.py) binds these with
+ * ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless it says "host";
+ *   - plain pointers and sizes only, no framework types; all functions return an int status
+ *     (EVDR_OK == 0) and never throw/abort across the ABI; evdr_last_error() gives the text;
+ *   - nothing here allocates, frees or synchronises: scratch memory comes in through
+ *     `workspace` (query the size first), work is enqueued on `hip_stream` (a hipStream_t, may
+ *     be NULL for the default stream) and the call returns immediately (graph-capture safe);
+ *   - D (embedding width) must be 128 (ColPali / ColQwen projection width);
+ *   - masks are one byte per token, 0 = masked (torch.bool storage);
+ *   - dtype: EVDR_F32 inputs are scored to fp32 accuracy (3-way bf16 split, 6 MFMA products,
+ *     error ~1e-7 relative); EVDR_BF16 inputs are used as they are (products exact in fp32).
+ */
+#ifndef EVDR_H
+#define EVDR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVDR_OK            0
+#define EVDR_ERR_ARG       1   /* null pointer / bad enum / negative size            */
+#define EVDR_ERR_SHAPE     2   /* unsupported shape (D != 128, Lp > 65535 w/ argmax) */
+#define EVDR_ERR_WORKSPACE 3   /* workspace missing or too small                     */
+#define EVDR_ERR_HIP       4   /* a HIP runtime call or kernel launch failed         */
+
+#define EVDR_F32  0
+#define EVDR_BF16 1
+
+#define EVDR_TOPK_MAX 128      /* k_values max is 100 (evaluator/retrieval.py:223)   */
+
+int         evdr_version(void);          /* 10000*major + 100*minor + patch */
+const char* evdr_last_error(void);       /* host string, thread-local, valid until the next call */
+
+/* ---- corpus preparation (the steps either side of the hot loop; cacheable for a static corpus) ---- */
+
+/* Pack a (np, lp) byte mask into per-32-patch tile words + per-page flags.
+ * tilemask: np * ceil(lp/32) uint32 (bit m of word t = pmask[p][32 t + m]);
+ * pageflags: np uint32 (bit0 = page has a valid patch  [doc_has_token, evaluator/retrieval.py:192],
+ *                       bit1 = page has a masked patch [-1e4 fill takes part in the max, :198],
+ *                       bits 16..31 = index of the first masked patch). */
+int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp,
+                    uint32_t* tilemask, uint32_t* pageflags, void* hip_stream);
+
+/* Split `rows` x 128 fp32 into three bf16 planes hi/mid/lo with x == hi + mid + lo (to 2^-24 rel.).
+ * planes: 3 * rows * 128 uint16 (bf16 bits), plane-major. */
+int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, void* hip_stream);
+
+/* ---- A1: score_multi_vector_masked (evaluator/retrieval.py:166-213) ---------------------------------
+ * out[q,p] = sum_n qmask[q,n] * has(p) * max_m( Q[q,n,:]·P[p,m,:] if pmask[p,m] else -1e4 )
+ * Q (nq,lq,128), P (np,lp,128) of `dtype`, row-major, contiguous in the last two dims;
+ * strides_or_null = {q_stride, p_stride} in ELEMENTS between consecutive queries / pages
+ * (NULL = dense).  qmask (nq,lq) / pmask (np,lp) bytes; either may be NULL = all valid.
+ * out (nq,np) fp32 dense.  argmax_or_null: (nq,np,lq) uint16, first maximal patch index per
+ * query token (what torch.max picks, :201) -- needed only for evdr_maxsim_bwd.
+ * chunk_p of the reference is a memory knob with no numerical effect and has no counterpart. */
+size_t evdr_maxsim_fwd_workspace(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype);
+int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const uint8_t* pmask,
+                    float* out, uint16_t* argmax_or_null,
+                    int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d, int dtype,
+                    const int64_t* strides_or_null,
+                    void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Same computation on a PREPARED (resident) corpus: bf16 planes + packed masks made once with
+ * evdr_split_f32 / evdr_pack_pmask.  nplanes = 1 (bf16 corpus) or 3 (fp32 split).  Q planes are
+ * (nplanes, nq, lq, 128) bf16; P planes are nplanes slabs `p_plane_stride` elements apart, each
+ * (np, lp, 128) with `p_stride` elements between pages.  out row stride = out_stride floats, so a
+ * shard can write its column block of a wider (nq, N) matrix.  This is the bench / retrieval
+ * hot path (SURVEY §8(d),(e)). */
+int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes,
+                             const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
+                             float* out, int64_t out_stride, uint16_t* argmax_or_null,
+                             int64_t nq, int64_t lq, int64_t np, int64_t lp,
+                             int nplanes, int64_t p_stride, int64_t p_plane_stride,
+                             void* hip_stream);
+
+/* ---- A6: autograd of A1 w.r.t. P (loss.backward(), mainv2_iter_distill_infonce.py:290) ---------------
+ * dP[p,m,:] = sum_{q,n} g[q,p] * qmask[q,n] * has(p) * [m == argmax[q,p,n]] * Q[q,n,:]
+ * g (nq,np) fp32; Q (nq,lq,128) fp32; argmax from evdr_maxsim_fwd; dP (np,lp,128) fp32 is
+ * OVERWRITTEN (every element written, masked rows get exact zeros). */
+int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
+                    const uint16_t* argmax, float* dP,
+                    int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d, void* hip_stream);
+
+/* ---- A8: top-k per query row, replaces the Nq*N .item() loop (mainv2_iter_distill_infonce.py:311-317)
+ * scores (nq, n) fp32 with row stride `row_stride`; idx_map_or_null (nq, n) int32 maps a column to
+ * the index to report (used when merging per-shard candidate lists), else column + idx_base.
+ * Order: score descending, reported index ascending on ties.  k <= EVDR_TOPK_MAX.
+ * top_scores/top_idx (nq, k); rows with n < k are padded with (-inf, -1). */
+int evdr_topk(const float* scores, const int32_t* idx_map_or_null, int64_t nq, int64_t n,
+              int64_t row_stride, int32_t idx_base, int k,
+              float* top_scores, int32_t* top_idx, void* hip_stream);
+
+/* A1 + A8 in one call on a prepared corpus: scores land in `workspace` (nq*np floats). */
+size_t evdr_maxsim_topk_workspace(int64_t nq, int64_t np);
+int evdr_maxsim_topk(const uint16_t* Qplanes, const uint16_t* Pplanes,
+                     const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
+                     int64_t nq, int64_t lq, int64_t np, int64_t lp,
+                     int nplanes, int64_t p_stride, int64_t p_plane_stride,
+                     int32_t idx_base, int k, float* top_scores, int32_t* top_idx,
+                     void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* ---- A5 (+ its gradient): infonce_distillation_loss (criterion.py:56-68) -----------------------------
+ * loss = mean_b CE(score_s[b,:]/temperature, argmax_p score_t[b,:]);
+ * dscore[b,p] = (softmax(score_s[b,:]/temperature)[p] - [p == target_b]) / (temperature * B).
+ * score_s/score_t (b, n) fp32 dense; loss: 1 float (device); dscore_or_null (b, n);
+ * row_loss: b floats of scratch (device). */
+int evdr_infonce_distill_fwd_bwd(const float* score_s, const float* score_t, int64_t b, int64_t n,
+                                 float temperature, float* loss, float* dscore_or_null,
+                                 float* row_loss, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVDR_H */

@@ -1,0 +1,67 @@
+"""The C-ABI library loads on a CPU-only host and exports exactly what include/evdr.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import evdr_amd  # noqa: F401
+    from evdr_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "evdr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(evdr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from evdr_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/evdr.h but not exported by libevdr.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.py"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_version_and_error_string(lib):
+    assert lib.evdr_version() == 100
+    assert isinstance(lib.evdr_last_error(), bytes)
+
+
+def test_argument_errors_need_no_gpu(lib):
+    """Status codes come back (never an abort) before anything touches the device."""
+    from evdr_amd import _lib as L
+    rc = lib.evdr_maxsim_fwd(None, None, None, None, None, None, 4, 8, 4, 8, 64, L.EVDR_BF16, None, None, 0, None)
+    assert rc == L.EVDR_ERR_SHAPE and b"128" in lib.evdr_last_error()
+    rc = lib.evdr_maxsim_fwd(None, None, None, None, None, None, 4, 8, 4, 8, 128, 7, None, None, 0, None)
+    assert rc == L.EVDR_ERR_ARG
+    rc = lib.evdr_maxsim_fwd(None, None, None, None, None, None, 4, 8, 4, 8, 128, L.EVDR_BF16, None, None, 0, None)
+    assert rc == L.EVDR_ERR_ARG          # null Q/P/out
+    rc = lib.evdr_maxsim_fwd(None, None, None, None, None, None, -1, 8, 4, 8, 128, L.EVDR_BF16, None, None, 0, None)
+    assert rc == L.EVDR_ERR_ARG
+    rc = lib.evdr_maxsim_fwd(None, None, None, None, None, None, 0, 8, 4, 8, 128, L.EVDR_BF16, None, None, 0, None)
+    assert rc == L.EVDR_OK               # empty score matrix is fine
+    rc = lib.evdr_topk(None, None, 3, 10, 10, 0, 500, None, None, None)
+    assert rc == L.EVDR_ERR_ARG and b"k=500" in lib.evdr_last_error()
+    rc = lib.evdr_infonce_distill_fwd_bwd(None, None, 4, 4, ctypes.c_float(0.0), None, None, None, None)
+    assert rc == L.EVDR_ERR_ARG
+    assert lib.evdr_maxsim_fwd_workspace(8, 32, 64, 1030, L.EVDR_F32) > 3 * 64 * 1030 * 128 * 2
+    assert lib.evdr_maxsim_fwd_workspace(8, 32, 64, 1030, L.EVDR_BF16) < 64 * 1030 * 4
+    assert lib.evdr_maxsim_topk_workspace(10, 10) >= 400
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from evdr_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()

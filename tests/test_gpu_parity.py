@@ -1,0 +1,287 @@
+"""Parity of the HIP path (through the C ABI) against the golden fixtures and the CPU oracle.
+Tolerances (SURVEY §8(d) parity gates): scores |d| <= 1e-4 abs on identical inputs (observed ~2e-6);
+argmax / top-k indices bit-exact where ties are absent or resolved by the stated rule; train step:
+loss rtol 1e-5, grad atol 1e-6, AdamW-updated parameters atol 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+import golden_recipes as R
+from oracle import maxsim_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SCORE_ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import evdr_amd  # noqa: F401
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ER(dev):
+    import evdr_amd.evaluator.retrieval as er
+    return er
+
+
+def T(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+@pytest.mark.parametrize("case", ["small_ragged", "lq1", "chunk_tail"])
+@pytest.mark.parametrize("as_bf16", [False, True])
+def test_a1_small_forward(golden, dev, ER, case, as_bf16):
+    z = golden(f"a1_{case}")
+    Q, P, qm, pm, g = R.small_case(case)
+    cast = (lambda t: t.bfloat16()) if as_bf16 else (lambda t: t)       # values are bf16-representable
+    s = ER.score_multi_vector_masked(cast(Q).to(dev), cast(P).to(dev), qm.to(dev), pm.to(dev), chunk_p=R.SMALL_CHUNK[case])
+    assert s.dtype == torch.float32 and s.device.type == "cuda" and tuple(s.shape) == z["scores"].shape
+    np.testing.assert_allclose(s.cpu().numpy(), z["scores"], atol=SCORE_ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("case", ["small_ragged", "lq1", "chunk_tail"])
+def test_a6_small_backward_and_argmax(golden, dev, ER, case):
+    import evdr_amd.ops as ops
+    z = golden(f"a1_{case}")
+    Q, P, qm, pm, g = R.small_case(case)
+    Pd = P.to(dev).requires_grad_(True)
+    s = ER.score_multi_vector_masked(Q.to(dev), Pd, qm.to(dev), pm.to(dev))
+    (s * g.to(dev)).sum().backward()
+    np.testing.assert_allclose(s.detach().cpu().numpy(), z["scores"], atol=SCORE_ATOL, rtol=0)
+    np.testing.assert_allclose(Pd.grad.cpu().numpy(), z["dP"], atol=1e-6, rtol=0)
+    # known answers: masked positions / all-masked pages get EXACT zeros
+    assert torch.all(Pd.grad.cpu()[~pm] == 0)
+    # argmax: bit-exact vs torch.max of the reference, first index on ties (duplicates in page 1)
+    for as_bf16 in (False, True):
+        Qx, Px = (Q.bfloat16(), P.bfloat16()) if as_bf16 else (Q, P)
+        _, arg = ops.maxsim_forward(Qx.to(dev), Px.to(dev), qm.to(dev), pm.to(dev), want_argmax=True)
+        arg = arg.cpu().numpy().astype(np.int32) & 0xFFFF
+        live = pm.any(dim=1).numpy()                     # argmax of an all-masked page is irrelevant (weight 0)
+        assert np.array_equal(arg[:, live, :], z["argmax"][:, live, :])
+        assert np.array_equal(arg[:, ~live, :], z["argmax"][:, ~live, :])   # but it matches anyway: index 0
+
+
+def test_a1_all_masked_page_is_exact_zero(dev, ER):
+    Q, P, qm, pm, g = R.small_case("small_ragged")
+    s = ER.score_multi_vector_masked(Q.to(dev), P.to(dev), qm.to(dev), pm.to(dev)).cpu()
+    assert torch.all(s[:, 2] == 0.0)
+
+
+@pytest.mark.parametrize("tag,bf16", [("f32", False), ("bf16", True)])
+def test_a1_seeded_1030(golden, dev, ER, tag, bf16):
+    z = golden("a1_seeded1030_" + tag)
+    Q, P, qm, pm = R.seeded_1030(bf16_inputs=bf16)
+    if bf16:
+        Q, P = Q.bfloat16(), P.bfloat16()
+    s = ER.score_multi_vector_masked(Q.to(dev), P.to(dev), qm.to(dev), pm.to(dev), chunk_p=64)
+    np.testing.assert_allclose(s.cpu().numpy(), z["scores"], atol=SCORE_ATOL, rtol=0)
+    # observed accuracy is far inside the gate
+    assert np.abs(s.cpu().numpy() - z["scores"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("nq", [1, 5, 12, 33, 70])          # exercises the 1/2/4 queries-per-wave variants + ragged groups
+@pytest.mark.parametrize("lq,lp", [(32, 1030), (7, 45), (50, 100), (1, 64)])
+def test_a1_vs_oracle_shapes(dev, ER, nq, lq, lp):
+    gen = torch.Generator().manual_seed(nq * 1000 + lq * 10 + lp)
+    npg = 37
+    Q = torch.nn.functional.normalize(torch.randn(nq, lq, 128, generator=gen), dim=-1).bfloat16()
+    P = torch.nn.functional.normalize(torch.randn(npg, lp, 128, generator=gen), dim=-1).bfloat16()
+    qm = torch.rand(nq, lq, generator=gen) > 0.2
+    pm = torch.rand(npg, lp, generator=gen) > 0.3
+    pm[5] = False
+    pm[6] = True
+    want = O.maxsim_masked(Q.float(), P.float(), qm, pm)
+    got = ER.score_multi_vector_masked(Q.to(dev), P.to(dev), qm.to(dev), pm.to(dev)).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=SCORE_ATOL, rtol=0)
+    got32 = ER.score_multi_vector_masked(Q.float().to(dev), P.float().to(dev), qm.to(dev), pm.to(dev)).cpu()
+    np.testing.assert_allclose(got32.numpy(), want.numpy(), atol=SCORE_ATOL, rtol=0)
+
+
+def test_a1_fp32_path_accuracy(dev, ER):
+    """fp32 inputs NOT representable in bf16: the 3-plane path must track an fp64 computation like fp32 does."""
+    gen = torch.Generator().manual_seed(77)
+    Q = torch.nn.functional.normalize(torch.randn(16, 32, 128, generator=gen), dim=-1)
+    P = torch.nn.functional.normalize(torch.randn(64, 300, 128, generator=gen), dim=-1)
+    qm = torch.ones(16, 32, dtype=torch.bool)
+    pm = torch.ones(64, 300, dtype=torch.bool)
+    sim = torch.einsum("qnd,pmd->qpnm", Q.double(), P.double())
+    want = sim.amax(-1).sum(-1)
+    got = ER.score_multi_vector_masked(Q.to(dev), P.to(dev), qm.to(dev), pm.to(dev)).cpu().double()
+    ref32 = O.maxsim_masked(Q, P, qm, pm).double()
+    err_got, err_ref = (got - want).abs().max().item(), (ref32 - want).abs().max().item()
+    assert err_got < 1e-5, err_got
+    assert err_got < 10 * max(err_ref, 1e-6), (err_got, err_ref)
+
+
+def test_non_contiguous_and_nonbool_inputs(dev, ER):
+    gen = torch.Generator().manual_seed(8)
+    Pbig = torch.nn.functional.normalize(torch.randn(20, 40, 128, generator=gen), dim=-1).bfloat16()
+    Q = torch.nn.functional.normalize(torch.randn(9, 8, 128, generator=gen), dim=-1).bfloat16()
+    pm = (torch.rand(20, 40, generator=gen) > 0.3)
+    qm = torch.ones(9, 8)
+    Pd, pmd = Pbig.to(dev), pm.to(dev)
+    got = ER.score_multi_vector_masked(Q.to(dev), Pd[3:17], qm.to(dev), pmd[3:17].to(torch.int64))   # slice + int mask
+    want = O.maxsim_masked(Q.float(), Pbig[3:17].float(), qm, pm[3:17])
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=SCORE_ATOL)
+    got2 = ER.score_multi_vector_masked(Q.to(dev), Pd[::2], qm.to(dev), pmd[::2])                     # strided pages
+    want2 = O.maxsim_masked(Q.float(), Pbig[::2].float(), qm, pm[::2])
+    np.testing.assert_allclose(got2.cpu().numpy(), want2.numpy(), atol=SCORE_ATOL)
+
+
+def test_cpu_tensors_are_rejected(ER):
+    Q, P, qm, pm, g = R.small_case("chunk_tail")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ER.score_multi_vector_masked(Q, P, qm, pm)
+
+
+def test_a2_unmasked_lists(golden, dev, ER):
+    z = golden("a2_unmasked_lists")
+    qs, ps = R.ragged_lists_case()
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        q2, p2 = [q.to(dtype) for q in qs], [p.to(dtype) for p in ps]
+        s4 = ER.BaseVisualRetrieverProcessor.score_multi_vector(q2, p2, batch_size=4, device="cuda:0")
+        s128 = ER.BaseVisualRetrieverProcessor.score_multi_vector(q2, p2, batch_size=128, device="cuda:0")
+        assert s4.device.type == "cpu" and s4.dtype == torch.float32
+        tol = SCORE_ATOL if dtype != torch.float16 else 2e-2      # fp16 rounds the bf16-representable inputs
+        np.testing.assert_allclose(s4.numpy(), z["scores_bs4"], atol=tol)
+        np.testing.assert_allclose(s128.numpy(), z["scores_bs128"], atol=tol)
+    with pytest.raises(ValueError, match="No queries provided"):
+        ER.BaseVisualRetrieverProcessor.score_multi_vector([], ps, device="cuda:0")
+    with pytest.raises(ValueError, match="No passages provided"):
+        ER.BaseVisualRetrieverProcessor.score_multi_vector(qs, [], device="cuda:0")
+
+
+def test_a3_single_vector_on_gpu(golden, ER):
+    z = golden("a3_single")
+    qs, ps = R.single_vector_case()
+    s = ER.BaseVisualRetrieverProcessor.score_single_vector(qs, ps, device="cuda:0")
+    assert s.device.type == "cuda"
+    np.testing.assert_allclose(s.cpu().numpy(), z["scores"], atol=1e-4)
+
+
+def test_a5_infonce_kernel(golden, dev):
+    from evdr_amd.criterion import infonce_distillation_loss
+    z = golden("a5_infonce")
+    ss = T(z["score_s"]).to(dev).requires_grad_(True)
+    st = T(z["score_t"]).to(dev)
+    loss = infonce_distillation_loss(ss, st, temperature=float(z["temp"]))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=1e-5)
+    np.testing.assert_allclose(ss.grad.cpu().numpy(), z["dscore"], atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["b4n8", "b32n128"])
+def test_a7_train_step(golden, dev, ER, tag):
+    """mainv2_iter_distill_infonce.py:269-292 call pattern with the drop-in functions + torch AdamW."""
+    from evdr_amd.criterion import infonce_distillation_loss
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    z = golden("a7_step_" + tag)
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = [x.to(dev) if torch.is_tensor(x) else x for x in R.train_case(tag)]
+    Pt_norm = l2_normalize(Pt * pmt.unsqueeze(-1)).detach()
+    param = torch.nn.Parameter(Pbar0 * pms.unsqueeze(-1))
+    opt = torch.optim.AdamW([param], lr=hp["lr"], weight_decay=hp["wd"])
+    Psb = l2_normalize(param * pms.unsqueeze(-1))
+    with torch.no_grad():
+        sc_t = ER.score_multi_vector_masked(Qb, Pt_norm, qmb, pmt, 64)
+    sc_s = ER.score_multi_vector_masked(Qb, Psb, qmb, pms, 64)
+    loss = infonce_distillation_loss(sc_s, sc_t, temperature=hp["temp"])
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    grad = param.grad.detach().clone()
+    opt.step()
+    np.testing.assert_allclose(sc_t.cpu().numpy(), z["sc_t"], atol=SCORE_ATOL)
+    np.testing.assert_allclose(sc_s.detach().cpu().numpy(), z["sc_s"], atol=SCORE_ATOL)
+    np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=1e-5)
+    if tag == "b4n8":
+        np.testing.assert_allclose(grad.cpu().numpy(), z["grad"], atol=1e-6)
+        np.testing.assert_allclose(param.detach().cpu().numpy(), z["param_after"], atol=1e-6)
+    else:
+        np.testing.assert_allclose(grad[::8, ::8, ::4].cpu().numpy(), z["grad_sample"], atol=1e-6)
+        np.testing.assert_allclose(grad.norm().item(), float(z["grad_norm"]), rtol=1e-4)
+        np.testing.assert_allclose(param.detach()[::8, ::8, ::4].cpu().numpy(), z["param_sample"], atol=1e-6)
+        np.testing.assert_allclose(param.detach().norm().item(), float(z["param_norm"]), rtol=1e-5)
+
+
+# ---- top-k --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,k", [(500, 100), (37, 100), (100, 100), (5000, 10), (100001, 100), (1, 1)])
+def test_topk_vs_oracle(dev, n, k):
+    import evdr_amd.ops as ops
+    gen = torch.Generator().manual_seed(n + k)
+    s = torch.randn(9, n, generator=gen)
+    s[0, : n // 2] = 1.5                       # heavy ties at the top
+    s[1] = 0.0                                 # everything ties
+    s[2, ::3] = float("-inf")
+    s[3, : min(n, 7)] = -0.0                   # -0.0 ties with +0.0
+    s[3, min(n, 7):] = -1.0
+    if n > 3:
+        s[3, 3] = 0.0
+    ws, wi = O.topk_rows(s, k)
+    gs, gi = ops.topk(s.to(dev), k)
+    keff = min(k, n)
+    assert torch.equal(gi.cpu()[:, :keff], wi)
+    assert torch.equal(gs.cpu()[:, :keff] + 0.0, ws + 0.0)
+    if keff < k:
+        assert torch.all(gi.cpu()[:, keff:] == -1) and torch.all(torch.isinf(gs.cpu()[:, keff:]))
+
+
+def test_topk_idx_map_and_base(dev):
+    import evdr_amd.ops as ops
+    gen = torch.Generator().manual_seed(1)
+    s = torch.randn(4, 300, generator=gen)
+    s[:, 100:200] = s[:, 0:100]                # duplicates -> ties resolved by the REPORTED index
+    m = torch.arange(300).repeat(4, 1).to(torch.int32) + 7000
+    gs, gi = ops.topk(s.to(dev), 50, idx_map=m.to(dev))
+    ws, wi = O.topk_rows(s, 50)
+    assert torch.equal(gi.cpu(), wi + 7000)
+    gs2, gi2 = ops.topk(s.to(dev), 50, idx_base=123)
+    assert torch.equal(gi2.cpu(), wi + 123)
+    # strided rows: a column block of a wider matrix
+    wide = torch.randn(4, 1000, generator=gen).to(dev)
+    a, b = ops.topk(wide[:, 200:700], 20, idx_base=200)
+    c, d = O.topk_rows(wide.cpu()[:, 200:700], 20)
+    assert torch.equal(b.cpu(), d + 200)
+
+
+# ---- resident corpus / retrieval --------------------------------------------------------------------
+def test_corpus_score_and_topk(dev):
+    from evdr_amd.corpus import PageCorpus
+    gen = torch.Generator().manual_seed(5)
+    P = torch.nn.functional.normalize(torch.randn(300, 70, 128, generator=gen), dim=-1).bfloat16()
+    Q = torch.nn.functional.normalize(torch.randn(40, 32, 128, generator=gen), dim=-1).bfloat16()
+    pm = torch.rand(300, 70, generator=gen) > 0.1
+    qm = torch.rand(40, 32, generator=gen) > 0.1
+    want = O.maxsim_masked(Q.float(), P.float(), qm, pm)
+    corpus = PageCorpus.from_tensor(P.to(dev), pm.to(dev), idx_base=1000)
+    got = corpus.score(Q.to(dev), qm.to(dev))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=SCORE_ATOL)
+    ts, ti = corpus.topk(Q.to(dev), qm.to(dev), 100)
+    ws, wi = O.topk_rows(got.cpu(), 100)               # ranking of the device scores themselves: bit-exact
+    assert torch.equal(ti.cpu(), wi + 1000) and torch.equal(ts.cpu(), ws)
+    # fp32 corpus (3 planes) with fp32 queries
+    c32 = PageCorpus.from_tensor(P.float().to(dev), pm.to(dev))
+    got32 = c32.score(Q.float().to(dev), qm.to(dev))
+    np.testing.assert_allclose(got32.cpu().numpy(), want.numpy(), atol=SCORE_ATOL)
+    with pytest.raises(RuntimeError, match="bf16 corpus needs bf16 queries"):
+        corpus.score(Q.float().to(dev), qm.to(dev))
+
+
+def test_sharded_merge_equals_single_shard(dev):
+    """Shards scored separately + candidate merge == one big shard (the N>1 data path, minus the wire)."""
+    from evdr_amd.corpus import PageCorpus, shard_range, pack_candidates, unpack_candidates, merge_candidates
+    gen = torch.Generator().manual_seed(6)
+    npg, world, k = 203, 4, 50
+    P = torch.nn.functional.normalize(torch.randn(npg, 40, 128, generator=gen), dim=-1).bfloat16().to(dev)
+    P[50:60] = P[150:160]                                  # cross-shard exact ties
+    Q = torch.nn.functional.normalize(torch.randn(17, 32, 128, generator=gen), dim=-1).bfloat16().to(dev)
+    full = PageCorpus.from_tensor(P)
+    fs, fi = full.topk(Q, None, k)
+    msgs = []
+    for r in range(world):
+        lo, hi = shard_range(npg, r, world)
+        sh = PageCorpus.from_tensor(P[lo:hi], None, idx_base=lo)
+        msgs.append(pack_candidates(*sh.topk(Q, None, k)))
+    sc, ix = unpack_candidates(torch.stack(msgs))
+    ms, mi = merge_candidates(sc, ix, k)
+    assert torch.equal(mi, fi) and torch.equal(ms, fs)

@@ -1,0 +1,133 @@
+"""Host-side logic that needs no GPU: metrics, sharding arithmetic, candidate packing, input checks."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maxsim_oracle as O
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import evdr_amd  # noqa: F401
+    import evdr_amd.evaluator.retrieval as er
+    return er
+
+
+def random_run(seed, nq=40, nd=120, multi_rel=False, ties=False):
+    rng = np.random.default_rng(seed)
+    docids = [f"doc{j}" for j in range(nd)]
+    results, qrels = {}, {}
+    for i in range(nq):
+        sc = rng.normal(size=nd)
+        if ties:
+            sc = np.round(sc, 1)
+        results[f"q{i}"] = {d: float(s) for d, s in zip(docids, sc)}
+        rel = {docids[int(rng.integers(nd))]: 1}
+        if multi_rel:
+            for j in rng.integers(nd, size=3):
+                rel[docids[int(j)]] = int(rng.integers(1, 4))
+        qrels[f"q{i}"] = rel
+    qrels["q_unscored"] = {"doc0": 1}
+    return qrels, results
+
+
+@pytest.mark.parametrize("multi_rel,ties", [(False, False), (True, False), (True, True)])
+def test_metrics_match_oracle(pkg, multi_rel, ties):
+    qrels, results = random_run(3, multi_rel=multi_rel, ties=ties)
+    ev = pkg.CustomRetrievalEvaluator()
+    got = ev.compute_mteb_metrics(qrels, results)
+    want = O.trec_metrics(qrels, results, ev.k_values)
+    assert set(got) == {"NDCG", "mAP", "Recall", "Precision", "mRR"}
+    for fam in want:
+        assert got[fam].keys() == want[fam].keys()
+        for k in want[fam]:
+            assert got[fam][k] == pytest.approx(want[fam][k], abs=1.1e-5), (fam, k)
+    assert "NDCG@5" in got["NDCG"] and "Recall@1" in got["Recall"]          # keys read by the train scripts
+
+
+def test_metrics_single_relevant_closed_form(pkg):
+    """nDCG@5 = 1/log2(1+rank) if rank <= 5 else 0 -- independent of any library (parity unpinned vs mteb)."""
+    rng = np.random.default_rng(0)
+    nd = 50
+    qrels, results, want = {}, {}, []
+    for i in range(200):
+        sc = rng.permutation(nd).astype(float)
+        tgt = int(rng.integers(nd))
+        rank = int((sc > sc[tgt]).sum()) + 1
+        want.append(1 / math.log2(1 + rank) if rank <= 5 else 0.0)
+        results[str(i)] = {f"d{j}": float(sc[j]) for j in range(nd)}
+        qrels[str(i)] = {f"d{tgt}": 1}
+    got = pkg.CustomRetrievalEvaluator().compute_mteb_metrics(qrels, results)
+    assert got["NDCG"]["NDCG@5"] == round(float(np.mean(want)), 5)
+
+
+def test_metrics_tie_rule_docid_descending(pkg):
+    qrels = {"q": {"a": 1}}
+    results = {"q": {"a": 1.0, "b": 1.0, "c": 0.5}}
+    m = pkg.CustomRetrievalEvaluator(k_values=[1, 3]).compute_mteb_metrics(qrels, results)
+    assert m["Recall"]["Recall@1"] == 0.0      # trec_eval ranks "b" above "a" on equal scores
+    assert m["Recall"]["Recall@3"] == 1.0
+
+
+def test_results_from_topk(pkg):
+    from evdr_amd.evaluator.metrics import results_from_topk
+    ts = np.array([[3.0, 2.0, -np.inf]], dtype=np.float32)
+    ti = np.array([[2, 0, -1]], dtype=np.int32)
+    r = results_from_topk(ts, ti, ["q7"], ["d0", "d1", "d2"])
+    assert r == {"q7": {"d2": 3.0, "d0": 2.0}}
+
+
+def test_shard_range_partitions():
+    from evdr_amd.corpus import shard_range
+    for n in (0, 1, 7, 100000, 100003):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(0 <= lo <= hi for lo, hi in spans)
+
+
+def test_candidate_pack_roundtrip():
+    from evdr_amd.corpus import pack_candidates, unpack_candidates
+    g = torch.Generator().manual_seed(0)
+    world, nq, k = 3, 5, 4
+    sc = [torch.randn(nq, k, generator=g) for _ in range(world)]
+    ix = [torch.randint(0, 1000, (nq, k), generator=g, dtype=torch.int32) for _ in range(world)]
+    buf = torch.stack([pack_candidates(s, i) for s, i in zip(sc, ix)])
+    s2, i2 = unpack_candidates(buf)
+    assert torch.equal(s2, torch.cat(sc, dim=1)) and torch.equal(i2, torch.cat(ix, dim=1))
+
+
+def test_list_scorers_errors_and_cpu_single_vector(pkg):
+    import golden_recipes as R
+    qs, ps = R.single_vector_case()
+    s = pkg.BaseVisualRetrieverProcessor.score_single_vector(qs, ps, device="cpu")      # config 0: CPU plumbing
+    assert s.dtype == torch.float32 and tuple(s.shape) == (7, 11)
+    np.testing.assert_allclose(s.numpy(), O.dot_single_vector(qs, ps).numpy(), atol=1e-5)
+    with pytest.raises(ValueError, match="No queries provided"):
+        pkg.BaseVisualRetrieverProcessor.score_single_vector([], ps, device="cpu")
+    with pytest.raises(ValueError, match="No passages provided"):
+        pkg.BaseVisualRetrieverProcessor.score_single_vector(qs, [], device="cpu")
+    with pytest.raises(ValueError, match="No queries provided"):
+        pkg.BaseVisualRetrieverProcessor.score_multi_vector([], ps)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.BaseVisualRetrieverProcessor.score_multi_vector([torch.zeros(3, 128)], [torch.zeros(5, 128)], device="cpu")
+    with pytest.raises(TypeError):
+        pkg.BaseVisualRetrieverProcessor()          # abstract, like the reference
+
+
+def test_masked_scorer_rejects_cpu_and_wrong_width(pkg):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.score_multi_vector_masked(torch.zeros(2, 3, 128), torch.zeros(2, 5, 128), torch.ones(2, 3), torch.ones(2, 5))
+
+
+def test_l2_normalize_matches_golden(golden):
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    z = golden("a4_l2norm")
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    y = l2_normalize(x)
+    np.testing.assert_allclose(y.detach().numpy(), z["y"], atol=1e-7, rtol=1e-6)
+    y.sum().backward()
+    assert torch.isfinite(x.grad).all()             # zero rows: subgradient 0, not NaN
