@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: late-interaction retrieval over a synthetic 100k-page corpus (BASELINE.json configs[3]).
+
+One "step" = one pass of the hot path over one query batch: 1024 queries (32 tokens x 128 dims, bf16) are
+scored against EVERY page of the corpus (1030 patches x 128 dims bf16 per page, resident in HBM), each rank
+keeps its shard's top-100 per query, one all-gather (RCCL) exchanges the candidates and every rank merges.
+The corpus is sharded by pages over the N ranks (strong scaling: 100k pages in total whatever N is).
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = query-page pairs scored per second
+over the whole job, plus `roofline` (dominant kernel = the fused MaxSim MFMA kernel, timed with HIP events on
+the launch stream) and `cpu_baseline` (the oracle's torch-CPU restatement of the reference scorer, timed on
+this box's host cores on a bounded slice; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 20261004
+LP, D, LQ = 1030, 128, 32
+FLOP_PER_PAIR = 2 * LQ * LP * D            # 8 437 760
+MFMA_BF16_PEAK_TFLOPS = 2500.0             # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
+GEN_CHUNK = 100                            # pages per deterministic generation chunk
+
+
+def gen_pages(lo: int, hi: int, dev) -> torch.Tensor:
+    """Pages [lo, hi) of the synthetic corpus: unit-norm Gaussian patches rounded to bf16.  Chunk-seeded, so a
+    page's content does not depend on how the corpus is sharded."""
+    out = torch.empty((hi - lo, LP, D), dtype=torch.bfloat16, device=dev)
+    g = torch.Generator(device=dev)
+    c0 = lo // GEN_CHUNK
+    c1 = (hi + GEN_CHUNK - 1) // GEN_CHUNK
+    for c in range(c0, c1):
+        g.manual_seed(SEED + c)
+        x = torch.randn((GEN_CHUNK, LP, D), generator=g, device=dev)
+        x = torch.nn.functional.normalize(x, dim=-1).bfloat16()
+        a, b = max(lo, c * GEN_CHUNK), min(hi, (c + 1) * GEN_CHUNK)
+        out[a - lo:b - lo] = x[a - c * GEN_CHUNK:b - c * GEN_CHUNK]
+    return out
+
+
+def make_queries(nq: int, n_pages: int, shard, lo: int, hi: int, dev, world: int):
+    """Planted queries: query i targets page t_i = (i*7919) mod N; token n = normalise(P[t_i, pi_i(n)]
+    + 0.5 eps).  Each rank fills the queries whose target lives in its shard; an all-reduce (setup, untimed) sums."""
+    import torch.distributed as dist
+    g = torch.Generator(device="cpu").manual_seed(SEED - 1)
+    targets = (torch.arange(nq) * 7919) % n_pages
+    rows = torch.stack([torch.randperm(LP, generator=g)[:LQ] for _ in range(nq)])          # (nq, LQ)
+    eps = torch.nn.functional.normalize(torch.randn((nq, LQ, D), generator=g), dim=-1)      # unit-norm noise
+    Q = torch.zeros((nq, LQ, D), dtype=torch.float32, device=dev)
+    mine = ((targets >= lo) & (targets < hi)).nonzero().flatten()
+    if len(mine):
+        t_local = (targets[mine] - lo).to(dev)
+        base = shard[t_local[:, None], rows[mine].to(dev)].float()                          # (m, LQ, D)
+        Q[mine.to(dev)] = torch.nn.functional.normalize(base + 0.5 * eps[mine].to(dev), dim=-1)
+    if world > 1:
+        dist.all_reduce(Q)
+    return Q.bfloat16(), targets
+
+
+def host_cores() -> int:
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box hands one
+    GPU's job a 16-core share of a 256-thread host) -- oversubscribing MKL beyond it is several times slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("EVDR_CPU_THREADS", "16"))))
+
+
+def cpu_baseline_leg(dev_corpus_slice: torch.Tensor, Qdev: torch.Tensor):
+    """The reference's scorer as restated in oracle/ (torch fp32 on the host, chunk_p=64), on a bounded slice of the
+    SAME workload: 32 queries x 2048 pages.  A reported baseline, not a target."""
+    from oracle import maxsim_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    P = dev_corpus_slice.float().cpu()
+    Q = Qdev[:32].float().cpu()
+    qm = torch.ones(Q.shape[:2], dtype=torch.bool)
+    pm = torch.ones(P.shape[:2], dtype=torch.bool)
+    O.maxsim_masked(Q[:4], P[:64], qm[:4], pm[:64], chunk_p=64)            # warm the thread pool
+    t0 = time.perf_counter()
+    s = O.maxsim_masked(Q, P, qm, pm, chunk_p=64)
+    dt = time.perf_counter() - t0
+    pairs = Q.shape[0] * P.shape[0]
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{Q.shape[0]} queries x {P.shape[0]} pages of the same corpus, chunk_p=64, torch fp32 CPU, "
+                      f"{dt:.2f} s, {cores} threads"}, s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pages", type=int, default=100000, help="total corpus pages (headline config: 100000)")
+    ap.add_argument("--queries", type=int, default=1024, help="queries per step")
+    ap.add_argument("--topk", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import evdr_amd  # noqa: F401
+    from evdr_amd.corpus import PageCorpus, ShardedRetriever, shard_range
+    from evdr_amd.evaluator.retrieval import CustomRetrievalEvaluator
+    from evdr_amd.evaluator.metrics import results_from_topk
+
+    # ---- resident corpus shard + replicated queries (setup, untimed)
+    lo, hi = shard_range(args.pages, rank, world)
+    shard_pages = gen_pages(lo, hi, dev)
+    corpus = PageCorpus.from_tensor(shard_pages, None, idx_base=lo)
+    Q, targets = make_queries(args.queries, args.pages, shard_pages, lo, hi, dev, world)
+    retriever = ShardedRetriever(corpus)
+
+    def step():
+        return retriever.search(Q, None, args.topk)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts, ti = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    pairs_per_step = args.queries * args.pages
+    value = pairs_per_step / (ms_per_step * 1e-3)
+
+    # ---- roofline of the dominant kernel: HIP events around the MaxSim launch on its own stream
+    out = torch.empty((args.queries, corpus.n_pages), dtype=torch.float32, device=dev)
+    corpus.score(Q, None, out=out)
+    torch.cuda.synchronize()
+    reps = 3
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        corpus.score(Q, None, out=out)
+        b.record()
+    torch.cuda.synchronize()
+    k_ms = sum(a.elapsed_time(b) for a, b in ev) / reps
+    flop_per_launch = args.queries * corpus.n_pages * FLOP_PER_PAIR
+    achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            rec = json.load(open(tpath))
+            if rec.get("queries") == args.queries and rec.get("pages_per_gpu") == corpus.n_pages:
+                traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                "kernel": "maxsim_fwd_kernel<QW=4,NPL=1>", "kernel_ms": k_ms,
+                "algorithmic_flop_per_launch": flop_per_launch,
+                "algorithmic_bytes_per_launch": corpus.n_pages * LP * D * 2}
+
+    # ---- quality on the planted queries (rank 0; uses the merged top-k of the last step)
+    ndcg5 = None
+    cpu_base = None
+    if rank == 0:
+        docids = [f"doc{j}" for j in range(args.pages)]
+        qrels = {str(i): {docids[int(t)]: 1} for i, t in enumerate(targets.tolist())}
+        res = results_from_topk(ts.cpu().numpy(), ti.cpu().numpy(), [str(i) for i in range(args.queries)], docids)
+        ndcg5 = CustomRetrievalEvaluator().compute_mteb_metrics(qrels, res)["NDCG"]["NDCG@5"]
+        if world == 1 and not args.no_cpu_baseline:
+            n_cpu = min(2048, corpus.n_pages)
+            cpu_base, s_cpu = cpu_baseline_leg(shard_pages[:n_cpu], Q)
+            dmax = (out[:32, :n_cpu].cpu() - s_cpu).abs().max().item()      # same inputs: the oracle as checker
+            cpu_base["max_abs_diff_vs_gpu"] = dmax
+        line = {
+            "metric": "query-page pairs scored/sec", "value": value, "unit": "pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "synthetic 100k-page late-interaction retrieval (BASELINE.json configs[3]): "
+                                   "MaxSim of every query against every page + per-shard top-k + all-gather merge",
+                       "pages": args.pages, "patches_per_page": LP, "dim": D, "queries_per_step": args.queries,
+                       "query_tokens": LQ, "topk": args.topk, "parallelism": f"page-shard x{world}"},
+            "queries_per_sec": args.queries / (ms_per_step * 1e-3), "ndcg_at_5": ndcg5,
+            "roofline": roofline, "cpu_baseline": cpu_base,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,7 +64,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __global__ void __launch_bounds__(256) infonce_row_kernel(const float* __restrict__ ss, const float* __restrict__ st,
-                                                         int64_t n, float inv_temp, float inv_tb,
+                                                         int64_t n, float temp, float inv_tb,
                                                          float* __restrict__ row_loss, float* __restrict__ dscore) {
     __shared__ float red[4];
     __shared__ int redi[4];
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) infonce_row_kernel(const float* __restric
     for (int64_t i = tid; i < n; i += 256) {
         const float tv = t[i];
         if (tv > tbest) { tbest = tv; tidx = (int)i; }
-        smax = fmaxf(smax, s[i] * inv_temp);
+        smax = fmaxf(smax, s[i] / temp);
     }
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(tbest, o);
@@ -96,18 +96,18 @@ __global__ void __launch_bounds__(256) infonce_row_kernel(const float* __restric
     smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float sum = 0.f;
-    for (int64_t i = tid; i < n; i += 256) sum += expf(s[i] * inv_temp - smax);
+    for (int64_t i = tid; i < n; i += 256) sum += expf(s[i] / temp - smax);
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
     sum = red[0] + red[1] + red[2] + red[3];
     const float lse = smax + logf(sum);
-    if (tid == 0) row_loss[blockIdx.x] = lse - s[tidx] * inv_temp;
+    if (tid == 0) row_loss[blockIdx.x] = lse - s[tidx] / temp;
     if (dscore != nullptr) {
         float* d = dscore + (int64_t)blockIdx.x * n;
         const float inv_sum = 1.f / sum;
         for (int64_t i = tid; i < n; i += 256) {
-            const float pr = expf(s[i] * inv_temp - smax) * inv_sum;
+            const float pr = expf(s[i] / temp - smax) * inv_sum;
             d[i] = (pr - ((int)i == tidx ? 1.f : 0.f)) * inv_tb;
         }
     }
@@ -138,7 +138,7 @@ hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t*
 hipError_t evdr_launch_infonce(const float* ss, const float* st, int64_t b, int64_t n, float temperature, float* loss,
                                float* dscore, float* row_loss, hipStream_t stream) {
     if (b == 0) return hipSuccess;
-    hipLaunchKernelGGL(infonce_row_kernel, dim3((unsigned)b), dim3(256), 0, stream, ss, st, n, 1.f / temperature,
+    hipLaunchKernelGGL(infonce_row_kernel, dim3((unsigned)b), dim3(256), 0, stream, ss, st, n, temperature,
                        1.f / (temperature * (float)b), row_loss, dscore);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -124,9 +124,10 @@ def main():
                  param_after=param.detach())
         else:  # big tensors: keep scores, loss and a strided sample + norms of grad/param
             save("a7_step_" + tag, loss=loss.detach(), sc_t=sc_t, sc_s=sc_s.detach(),
-                 grad_sample=grad[::8, ::8, ::4].contiguous(), grad_norm=grad.norm(),
+                 grad_sample=grad[::8, ::8, ::4].contiguous(), grad_norm=grad.double().norm(),
                  grad_abs_sum=grad.abs().sum(),
-                 param_sample=param.detach()[::8, ::8, ::4].contiguous(), param_norm=param.detach().norm())
+                 param_sample=param.detach()[::8, ::8, ::4].contiguous(),
+                 param_norm=param.detach().double().norm())   # float64: an fp32 norm over 3.4M values is only good to ~1e-4
 
     # ---- A3 single vector ---------------------------------------------------------------------
     qs, ps = R.single_vector_case()

