@@ -37,6 +37,7 @@ struct EvdrFwdParams {
 
 // launches (defined in the .hip files; all enqueue on `stream` and return the launch status)
 hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& p, int nplanes, bool want_argmax, hipStream_t stream);
+hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int geom, hipStream_t stream);
 hipError_t evdr_launch_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, uint32_t* tilemask,
                                   uint32_t* pageflags, hipStream_t stream);
 hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes, hipStream_t stream);

@@ -15,6 +15,8 @@
 //     8*QW queries, and the block->(query group, page chunk) map puts the query groups that share a
 //     page chunk on one XCD so the chunk is served by that XCD's L2;
 //   * NPL = 3 scores fp32 inputs to fp32 accuracy as six bf16 plane products (hi/mid/lo split).
+#include <stdlib.h>
+
 #include "evdr_common.h"
 
 namespace {
@@ -293,6 +295,14 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
     p.ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     int qw = 1;
     if (nplanes == 1) qw = (p.nq > 16) ? 4 : (p.nq > 8 ? 2 : 1);
+    if (nplanes == 1 && !want_argmax) {
+        // bf16 scoring without argmax (retrieval / eval / teacher scores): the 16x16x32-shape kernel
+        // (maxsim_fwd16.hip).  EVDR_FWD_VARIANT is an experiment switch read per launch:
+        // 0/unset = default geometry, 1|2 = alternative ring geometries, 100 = this file's 32x32x16 kernel.
+        const char* e = getenv("EVDR_FWD_VARIANT");
+        const int variant = e ? atoi(e) : 0;
+        if (variant != 100) return evdr_launch_maxsim_fwd16(p, qw, variant, stream);
+    }
     p.n_qgroups = (p.nq + WAVES * qw - 1) / (WAVES * qw);
     int64_t ppb = ((int64_t)p.np * p.n_qgroups) / 1536;
     if (ppb < 1) ppb = 1;
