@@ -36,6 +36,9 @@ def import_reference():
                  "mteb.evaluation.evaluators.RetrievalEvaluator"]:
         sys.modules.setdefault(name, types.ModuleType(name))
     sys.modules["mteb.evaluation.evaluators.RetrievalEvaluator"].RetrievalEvaluator = object
+    tb = types.ModuleType("torch.utils.tensorboard")        # utils/utils.py:9 imports it at module level; absent here
+    tb.SummaryWriter = object
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
     sys.path.insert(0, REF)
     import criterion as ref_criterion
     import evaluator.retrieval as ref_retrieval
@@ -128,6 +131,38 @@ def main():
                  grad_abs_sum=grad.abs().sum(),
                  param_sample=param.detach()[::8, ::8, ::4].contiguous(),
                  param_norm=param.detach().double().norm())   # float64: an fp32 norm over 3.4M values is only good to ~1e-4
+
+    # ---- the six secondary losses of criterion.py (value + gradient w.r.t. the student scores) -------------
+    ss, st, labels = R.losses_case()
+    cases = {
+        "infonce_supervised_loss": lambda s: ref_criterion.infonce_supervised_loss(s, labels, temperature=0.07),
+        "score_preserving_loss": lambda s: ref_criterion.score_preserving_loss(s, st),
+        "pairwise_distillation_loss": lambda s: ref_criterion.pairwise_distillation_loss(s, st),
+        "listwise_distillation_loss": lambda s: ref_criterion.listwise_distillation_loss(s, st, k=10, temperature=2.0),
+        "lambda_loss": lambda s: ref_criterion.lambda_loss(s, st),
+        "ranknce_loss": lambda s: ref_criterion.ranknce_loss(s, st, temperature=0.5, lambda_weight=0.7),
+    }
+    arrays = {}
+    for name, fn in cases.items():
+        sg = ss.clone().requires_grad_(True)
+        val = fn(sg)
+        val.backward()
+        arrays[name] = val.detach()
+        arrays[name + "_grad"] = sg.grad
+    save("losses", **arrays)
+
+    # ---- npz schema helpers (utils/preprocess_data.py, utils/utils.py) -------------------------------------
+    import utils.utils as ref_utils
+    docs, attn, img, queries, qattn, docid = R.npz_payload_case()
+    P_raw, pmask, valid = ref_prep.preprocess_docs(docs, attn, img, device="cpu")
+    P_raw2, pmask2, _ = ref_prep.preprocess_docs(docs, None, None, device="cpu")
+    Qn, qmask = ref_prep.preprocess_queries(queries, qattn, device="cpu")
+    objs = ref_utils.tokens_to_object(P_raw.numpy(), pmask.numpy())
+    perm = np.array([3, 0, 6, 1, 5, 2, 4])
+    (docs_al,), ok = ref_utils.align_by_docid(docid, docid[perm], docs[perm])
+    save("npz_helpers", P_raw=P_raw, pmask=pmask, valid=valid, pmask_nomask=pmask2, Q=Qn, qmask=qmask,
+         obj_lens=np.array([o.shape[0] for o in objs]), obj_concat=np.concatenate(list(objs), axis=0),
+         align_ok=np.array(ok), align_first_rows=np.stack([d[0] for d in docs_al]))
 
     # ---- A3 single vector ---------------------------------------------------------------------
     qs, ps = R.single_vector_case()

@@ -130,3 +130,33 @@ def ragged_lists_case():
     qs = [_bf16r(_unit(gen, l, 128)) for l in qlens]
     ps = [_bf16r(_unit(gen, l, 128)) for l in plens]
     return qs, ps
+
+
+def losses_case():
+    """(B, N) student / teacher score matrices + labels for the six secondary losses."""
+    gen = torch.Generator().manual_seed(23)
+    ss = torch.randn(6, 40, generator=gen) * 1.5 + 8.0
+    st = torch.randn(6, 40, generator=gen) * 1.5 + 8.0
+    labels = torch.randint(0, 40, (6,), generator=gen)
+    return ss, st, labels
+
+
+def npz_payload_case():
+    """A small feature dump in the reference's object-array schema (ragged pages/queries, optional masks)."""
+    import numpy as np
+    rng = np.random.default_rng(31)
+    dlens, qlens = [5, 12, 9, 1, 12, 3, 8], [3, 7, 7, 2, 5]
+    def obj(items):
+        a = np.empty(len(items), dtype=object)
+        for i, v in enumerate(items):
+            a[i] = v
+        return a
+    docs = obj([rng.normal(size=(l, 128)).astype(np.float32) for l in dlens])
+    attn = obj([rng.random(l) > 0.15 for l in dlens])
+    img = obj([np.concatenate([np.zeros(min(2, l), bool), np.ones(max(l - 2, 0), bool)]) for l in dlens])
+    img[3] = np.ones((1, 1), dtype=np.int64)              # (Li,1) integer mask variant
+    queries = obj([rng.normal(size=(l, 128)).astype(np.float32) for l in qlens])
+    qattn = obj([np.ones(l, dtype=np.int64) for l in qlens])
+    qattn[1] = np.array([1, 1, 1, 0, 0, 1, 1])
+    docid = obj([f"doc_{i}" for i in range(len(dlens))])
+    return docs, attn, img, queries, qattn, docid

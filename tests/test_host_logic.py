@@ -131,3 +131,70 @@ def test_l2_normalize_matches_golden(golden):
     np.testing.assert_allclose(y.detach().numpy(), z["y"], atol=1e-7, rtol=1e-6)
     y.sum().backward()
     assert torch.isfinite(x.grad).all()             # zero rows: subgradient 0, not NaN
+
+
+def test_secondary_losses_match_reference(golden):
+    """criterion.py's other six losses (plain torch on the kernel's (B,N) outputs) vs the reference's values+grads."""
+    import golden_recipes as R
+    import evdr_amd.criterion as crit
+    z = golden("losses")
+    ss, st, labels = R.losses_case()
+    cases = {
+        "infonce_supervised_loss": lambda s: crit.infonce_supervised_loss(s, labels, temperature=0.07),
+        "score_preserving_loss": lambda s: crit.score_preserving_loss(s, st),
+        "pairwise_distillation_loss": lambda s: crit.pairwise_distillation_loss(s, st),
+        "listwise_distillation_loss": lambda s: crit.listwise_distillation_loss(s, st, k=10, temperature=2.0),
+        "lambda_loss": lambda s: crit.lambda_loss(s, st),
+        "ranknce_loss": lambda s: crit.ranknce_loss(s, st, temperature=0.5, lambda_weight=0.7),
+    }
+    for name, fn in cases.items():
+        sg = ss.clone().requires_grad_(True)
+        val = fn(sg)
+        val.backward()
+        np.testing.assert_allclose(val.item(), float(z[name]), rtol=1e-5, err_msg=name)
+        np.testing.assert_allclose(sg.grad.numpy(), z[name + "_grad"], atol=1e-6, rtol=1e-4, err_msg=name)
+
+
+def test_npz_helpers_match_reference(golden, tmp_path):
+    """utils/preprocess_data.py + utils/utils.py counterparts vs outputs of the reference's own functions."""
+    import golden_recipes as R
+    from evdr_amd.utils import preprocess_data as PD, utils as U
+    z = golden("npz_helpers")
+    docs, attn, img, queries, qattn, docid = R.npz_payload_case()
+    P_raw, pmask, valid = PD.preprocess_docs(docs, attn, img, device="cpu")
+    assert P_raw.dtype == torch.float32 and pmask.dtype == torch.bool
+    assert np.array_equal(P_raw.numpy(), z["P_raw"]) and np.array_equal(pmask.numpy(), z["pmask"])
+    assert np.array_equal(valid, z["valid"])
+    _, pm2, _ = PD.preprocess_docs(docs, None, None, device="cpu")
+    assert np.array_equal(pm2.numpy(), z["pmask_nomask"])
+    Q, qm = PD.preprocess_queries(queries, qattn, device="cpu")
+    np.testing.assert_allclose(Q.numpy(), z["Q"], atol=1e-7)
+    assert np.array_equal(qm.numpy(), z["qmask"])
+    objs = U.tokens_to_object(P_raw.numpy(), pmask.numpy())
+    assert np.array_equal(np.array([o.shape[0] for o in objs]), z["obj_lens"])
+    assert np.array_equal(np.concatenate(list(objs), axis=0), z["obj_concat"])
+    perm = np.array([3, 0, 6, 1, 5, 2, 4])
+    (docs_al,), ok = U.align_by_docid(docid, docid[perm], docs[perm])
+    assert ok == bool(z["align_ok"]) and np.array_equal(np.stack([d[0] for d in docs_al]), z["align_first_rows"])
+    assert U.align_by_docid(docid, docid[:3], docs[:3])[1] is False
+    # writer -> loader round trip in the reference's schema
+    path = tmp_path / "best_ndcg5.npz"
+    U.save_compressed_npz(path, docid, objs, attn, img, meta={"dataset": "synthetic", "mf": 5, "step": 1})
+    back = PD.load_init_payload(str(path))
+    assert [str(x) for x in back["docid"]] == [str(x) for x in docid]
+    assert all(np.array_equal(a, b) for a, b in zip(back["documents"], objs))
+    assert PD.load_npz(str(path))["meta"].item()["mf"] == 5
+
+
+def test_logger_line_contract(tmp_path):
+    """train.log lines must stay parseable by the reference's summary_results.py regex (JSON object at line end)."""
+    import json, re
+    from evdr_amd.utils.utils import get_logger, log_json
+    logger, tb = get_logger(tmp_path, use_tb=False)
+    log_json(logger, {"summary/best_ndcg5": {"step": 500, "Recall@1": 0.71, "NDCG@5": 0.83}, "note": "training finished"})
+    for h in logger.handlers:
+        h.flush()
+    line = (tmp_path / "train.log").read_text().strip().splitlines()[-1]
+    assert re.match(r"^\[[^\]]+\]\[INFO\] \{", line)
+    obj = json.loads(line[line.index("{"):])
+    assert obj["summary/best_ndcg5"]["NDCG@5"] == 0.83
