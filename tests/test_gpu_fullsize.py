@@ -1,0 +1,168 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties of the domain (the CPU oracle
+only sees samples it finishes in seconds): shard/merge == single shard, patch-permutation invariance, token
+additivity, idempotence, sortedness and score/index consistency of the top-k, planted-target recall."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maxsim_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LP, D, LQ = 1030, 128, 32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import evdr_amd  # noqa: F401
+    return torch.device("cuda:0")
+
+
+def synth(n_pages, n_q, dev, seed):
+    """bf16 unit-norm pages; queries planted on page (i*7919) % n_pages with unit noise of weight 0.5."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    P = torch.empty((n_pages, LP, D), dtype=torch.bfloat16, device=dev)
+    for lo in range(0, n_pages, 2000):
+        hi = min(lo + 2000, n_pages)
+        P[lo:hi] = torch.nn.functional.normalize(torch.randn((hi - lo, LP, D), generator=g, device=dev), dim=-1).bfloat16()
+    tgt = (torch.arange(n_q, device=dev) * 7919) % n_pages
+    rows = torch.stack([torch.randperm(LP, generator=g, device=dev)[:LQ] for _ in range(n_q)])
+    eps = torch.nn.functional.normalize(torch.randn((n_q, LQ, D), generator=g, device=dev), dim=-1)
+    Q = torch.nn.functional.normalize(P[tgt[:, None], rows].float() + 0.5 * eps, dim=-1).bfloat16()
+    return P, Q, tgt
+
+
+def test_config1_docvqa_shape_vs_oracle(dev):
+    """configs[1]: ~500 pages x 1030 patches, bf16.  64 queries x 500 pages against the oracle: scores, top-100
+    indices (where the ranking gap exceeds twice the score tolerance) and nDCG@5."""
+    import evdr_amd.ops as ops
+    from evdr_amd.evaluator.retrieval import score_multi_vector_masked, CustomRetrievalEvaluator
+    from evdr_amd.evaluator.metrics import results_from_topk
+    P, Q, tgt = synth(500, 64, dev, seed=11)
+    gen = torch.Generator().manual_seed(1)
+    pm = torch.ones(500, LP, dtype=torch.bool)
+    lens = torch.randint(700, LP + 1, (500,), generator=gen)             # ragged valid lengths
+    pm[torch.arange(LP)[None, :] >= lens[:, None]] = False
+    qm = torch.ones(64, LQ, dtype=torch.bool)
+    qm[:, 20:] = torch.rand(64, 12, generator=gen) > 0.5
+    got = score_multi_vector_masked(Q, P, qm.to(dev), pm.to(dev))
+    torch.set_num_threads(16)
+    want = O.maxsim_masked(Q.float().cpu(), P.float().cpu(), qm, pm, chunk_p=64)
+    assert (got.cpu() - want).abs().max().item() < 1e-4
+    ts, ti = ops.topk(got, 100)
+    ws, wi = O.topk_rows(want, 100)
+    gap_ok = (ws[:, :-1] - ws[:, 1:]) > 2e-4
+    safe = torch.cat([gap_ok, gap_ok[:, -1:]], 1) & torch.cat([gap_ok[:, :1], gap_ok], 1)
+    assert torch.equal(ti.cpu()[safe], wi[safe])
+    docids = [f"doc{j}" for j in range(500)]
+    qrels = {str(i): {docids[int(t)]: 1} for i, t in enumerate(tgt.tolist())}
+    ev = CustomRetrievalEvaluator()
+    m_gpu = ev.compute_mteb_metrics(qrels, results_from_topk(ts.cpu().numpy(), ti.cpu().numpy(), range(64), docids))
+    m_cpu = ev.compute_mteb_metrics(qrels, {str(i): {docids[j]: float(want[i, j]) for j in range(500)} for i in range(64)})
+    assert abs(m_gpu["NDCG"]["NDCG@5"] - m_cpu["NDCG"]["NDCG@5"]) <= 1e-4
+    assert abs(m_gpu["Recall"]["Recall@1"] - m_cpu["Recall"]["Recall@1"]) <= 1e-4
+
+
+def test_config2_full_vidore_size_properties(dev):
+    """configs[2]: the 10-subset corpus size (6 847 pages), 256 queries."""
+    import evdr_amd.ops as ops
+    from evdr_amd.corpus import PageCorpus, shard_range, pack_candidates, unpack_candidates, merge_candidates
+    n, nq, k = 6847, 256, 100
+    P, Q, tgt = synth(n, nq, dev, seed=12)
+    corpus = PageCorpus.from_tensor(P)
+    s1 = corpus.score(Q).clone()
+    s2 = corpus.score(Q)
+    assert torch.equal(s1, s2)                                           # idempotent, deterministic
+    assert torch.equal(s1.argmax(dim=1), tgt)                            # planted page is rank 1 for every query
+    # patches inside a page are a set: permuting them leaves every score bit-exact
+    perm = torch.randperm(LP, device=dev)
+    sp = PageCorpus.from_tensor(P[:512][:, perm].contiguous()).score(Q)
+    assert torch.equal(sp, s1[:, :512])
+    # token additivity: disjoint query-token masks add up
+    ma = torch.zeros(nq, LQ, dtype=torch.bool, device=dev)
+    ma[:, ::2] = True
+    sa = corpus.score(Q, ma)
+    sb = corpus.score(Q, ~ma)
+    assert (sa + sb - s1).abs().max().item() < 2e-5
+    # a random sample of pages against the oracle
+    cols = torch.randperm(n)[:48]
+    want = O.maxsim_masked(Q[:16].float().cpu(), P[cols.to(dev)].float().cpu(), torch.ones(16, LQ, dtype=torch.bool),
+                           torch.ones(48, LP, dtype=torch.bool))
+    assert (s1[:16][:, cols.to(dev)].cpu() - want).abs().max().item() < 1e-4
+    # top-k: sorted, consistent with the score matrix, and shard+merge == single shard (bit-exact)
+    ts, ti = corpus.topk(Q, None, k)
+    assert torch.all(ts[:, :-1] >= ts[:, 1:])
+    assert torch.equal(s1.gather(1, ti.long()), ts)
+    ws, wi = O.topk_rows(s1.cpu(), k)
+    assert torch.equal(ti.cpu(), wi)
+    msgs = []
+    for r in range(3):
+        lo, hi = shard_range(n, r, 3)
+        msgs.append(pack_candidates(*PageCorpus.from_tensor(P[lo:hi], None, idx_base=lo).topk(Q, None, k)))
+    ms, mi = merge_candidates(*unpack_candidates(torch.stack(msgs)), k)
+    assert torch.equal(mi, ti) and torch.equal(ms, ts)
+
+
+def test_config3_100k_pages_properties(dev):
+    """configs[3] at its full 100 000-page size on one GPU (26.4 GB resident), 64 queries."""
+    from evdr_amd.corpus import PageCorpus, shard_range, pack_candidates, unpack_candidates, merge_candidates
+    n, nq, k = 100000, 64, 100
+    P, Q, tgt = synth(n, nq, dev, seed=13)
+    corpus = PageCorpus.from_tensor(P)
+    ts, ti = corpus.topk(Q, None, k)
+    assert torch.equal(ti[:, 0].long(), tgt)                             # planted page retrieved at rank 1
+    assert torch.all(ts[:, :-1] >= ts[:, 1:])
+    s = corpus.score(Q)
+    assert torch.equal(s.gather(1, ti.long()), ts)
+    cols = torch.randperm(n)[:32]
+    want = O.maxsim_masked(Q[:8].float().cpu(), P[cols.to(dev)].float().cpu(), torch.ones(8, LQ, dtype=torch.bool),
+                           torch.ones(32, LP, dtype=torch.bool))
+    assert (s[:8][:, cols.to(dev)].cpu() - want).abs().max().item() < 1e-4
+    msgs = []
+    for r in range(8):                                                  # the 8-GPU sharding, replayed on one GPU
+        lo, hi = shard_range(n, r, 8)
+        shard = PageCorpus(corpus.planes[:, lo:hi], corpus.tilemask[lo:hi], corpus.pageflags[lo:hi], idx_base=lo)
+        msgs.append(pack_candidates(*shard.topk(Q, None, k)))
+    ms, mi = merge_candidates(*unpack_candidates(torch.stack(msgs)), k)
+    assert torch.equal(mi, ti) and torch.equal(ms, ts)
+
+
+def test_rccl_exchange_single_rank(dev):
+    """The candidate all-gather through the nccl (= RCCL) backend with device tensors; one rank is all a 1-GPU box has."""
+    import torch.distributed as dist
+    from evdr_amd.corpus import gather_candidates, merge_candidates
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        g = torch.Generator().manual_seed(2)
+        sc = torch.randn(20, 100, generator=g).sort(dim=1, descending=True).values.to(dev)
+        ix = torch.randint(0, 10000, (20, 100), generator=g, dtype=torch.int32).to(dev)
+        s2, i2 = gather_candidates(sc, ix)
+        assert torch.equal(s2, sc) and torch.equal(i2, ix)
+        ms, mi = merge_candidates(s2, i2, 100)
+        assert torch.equal(ms, sc)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_corpus_from_npz_payload(dev, tmp_path):
+    """Feature-dump object arrays -> resident corpus (bf16 and fp32) == the reference's preprocess_docs + l2_normalize path."""
+    import golden_recipes as R
+    from evdr_amd.utils import preprocess_data as PD
+    docs, attn, img, queries, qattn, docid = R.npz_payload_case()
+    P_raw, pmask, _ = PD.preprocess_docs(docs, attn, img, device="cpu")
+    Pn = O.l2_normalize(P_raw * pmask.unsqueeze(-1))
+    Q, qm = PD.preprocess_queries(queries, qattn, device="cpu")
+    want = O.maxsim_masked(Q, Pn, qm, pmask)
+    c32, pm32 = PD.corpus_from_payload(docs, attn, img, dev, dtype=torch.float32)
+    assert torch.equal(pm32.cpu(), pmask)
+    got = c32.score(Q.to(dev), qm.to(dev))
+    assert (got.cpu() - want).abs().max().item() < 1e-5
+    c16, _ = PD.corpus_from_payload(docs, attn, img, dev, dtype=torch.bfloat16)
+    got16 = c16.score(Q.bfloat16().to(dev), qm.to(dev))
+    want16 = O.maxsim_masked(Q.bfloat16().float(), Pn.bfloat16().float(), qm, pmask)
+    assert (got16.cpu() - want16).abs().max().item() < 1e-4
