@@ -1,0 +1,276 @@
+"""Train / eval driver for InfoNCE distillation of page embeddings: the counterpart of the call pattern and the log
+contract of the reference's `mainv2_iter_distill_infonce.py` (§5 "Metrics / logging").
+
+Not a port of that script: the step and the evaluation are organised around what is resident on the GPU.
+  * the frozen teacher pages are prepared ONCE as a resident corpus (bf16 hi/mid/lo planes + packed masks), so a
+    step never re-reads or re-splits the 1030-patch fp32 teacher tensor (the reference re-uploads nothing but
+    recomputes the teacher scores from fp32 every step, :283);
+  * evaluation ranks on the device (top-100 per query, two D2H copies) instead of `.item()`-ing every score into
+    a dict (:311-317); the reported latency is synchronised wall time per query;
+  * optional teacher-score cache keyed by training-query index: teacher scores are constant per query over the
+    whole run ("a legal, result-identical optimisation").
+What is kept exactly: the arithmetic of a step (masked MaxSim of teacher and student, CE against the teacher's
+top-1, AdamW on the raw student embeddings through l2_normalize and the mask), the CLI flags, the directory
+layout `<out_root>/<name>/mf<k>/<dataset>/`, `config.json`, `best_{recall,ndcg5}.npz`, and the `train.log` JSON
+lines including the final `"summary/best_ndcg5"` line that `summary_results.py:35,68-87` parses.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import time
+from pathlib import Path
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .corpus import PageCorpus
+from .criterion import infonce_distillation_loss
+from .evaluator.metrics import results_from_topk
+from .evaluator.retrieval import CustomRetrievalEvaluator, score_multi_vector_masked
+from .utils.preprocess_data import (_as_object_array, l2_normalize, load_init_payload, load_payload,
+                                    load_query_payload, preprocess_docs, preprocess_queries)
+from .utils.utils import align_by_docid, get_logger, log_json, save_compressed_npz, set_optimizer, set_seed, tokens_to_object
+
+
+class TeacherScorer:
+    """Frozen teacher pages as a resident fp32-accurate corpus; scores(Qb, qmb) -> (B, N) fp32, no autograd."""
+
+    def __init__(self, P_teacher_norm: torch.Tensor, pmask_teacher: torch.Tensor, cache_size: int = 0):
+        self.corpus = PageCorpus.from_tensor(P_teacher_norm.detach().float(), pmask_teacher)
+        self.cache: Optional[torch.Tensor] = None
+        self.have: Optional[torch.Tensor] = None
+        if cache_size > 0:
+            dev = P_teacher_norm.device
+            self.cache = torch.empty((cache_size, self.corpus.n_pages), dtype=torch.float32, device=dev)
+            self.have = torch.zeros(cache_size, dtype=torch.bool, device=dev)
+
+    @torch.no_grad()
+    def scores(self, Qb: torch.Tensor, qmb: torch.Tensor, qidx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.cache is None or qidx is None:
+            return self.corpus.score(Qb.float(), qmb)
+        qidx = qidx.to(self.cache.device)
+        if not bool(self.have[qidx].all()):
+            self.cache[qidx] = self.corpus.score(Qb.float(), qmb)
+            self.have[qidx] = True
+        return self.cache[qidx]
+
+
+def train_one_step(Qb, qmb, teacher, pmask_teacher, Pbar_param, pmask_student, opt, temp: float, chunk_p: int = 64,
+                   qidx: Optional[torch.Tensor] = None) -> float:
+    """One update, returns the loss (mainv2_iter_distill_infonce.py:269-292).  `teacher` is either the normalised
+    teacher tensor (reference signature) or a TeacherScorer (resident, preferred)."""
+    device = Pbar_param.device
+    Qb = Qb.to(device, non_blocking=True)
+    qmb = qmb.to(device, non_blocking=True)
+    Psb = l2_normalize(Pbar_param * pmask_student.unsqueeze(-1))
+    if isinstance(teacher, TeacherScorer):
+        sc_t = teacher.scores(Qb, qmb, qidx)
+    else:
+        with torch.no_grad():
+            sc_t = score_multi_vector_masked(Qb, teacher, qmb, pmask_teacher, chunk_p)
+    sc_s = score_multi_vector_masked(Qb, Psb, qmb, pmask_student, chunk_p)
+    loss = infonce_distillation_loss(sc_s, sc_t, temperature=temp)
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    return float(loss.item())
+
+
+@torch.no_grad()
+def eval_retrieval(evaluator: CustomRetrievalEvaluator, Q_test_norm, qmask_test, Pbar_param, pmask_student,
+                   relevant_docs_test, docidx_2_docid_test, qsidx_2_query_test, chunk_p: int = 64, k: int = 100):
+    """Retrieval metrics of the current student pages + "latency" (ms per query, synchronised)."""
+    P_now = l2_normalize(Pbar_param.detach() * pmask_student.unsqueeze(-1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scores = score_multi_vector_masked(Q_test_norm, P_now, qmask_test, pmask_student, chunk_p=chunk_p)
+    ts, ti = ops.topk(scores, min(k, 128))
+    torch.cuda.synchronize()
+    latency_ms = (time.perf_counter() - t0) * 1000 / max(Q_test_norm.shape[0], 1)
+    nq, n = scores.shape
+    qkeys = [str(qsidx_2_query_test[i]) if qsidx_2_query_test is not None else str(i) for i in range(nq)]
+    docids = [docidx_2_docid_test[str(j)] for j in range(n)]
+    results = results_from_topk(ts.cpu().numpy(), ti.cpu().numpy(), qkeys, docids)
+    metrics = evaluator.compute_mteb_metrics(relevant_docs_test, results)
+    metrics["latency"] = float(latency_ms)
+    return metrics
+
+
+@torch.no_grad()
+def evaluation_loss(Q_test_norm, qmask_test, teacher, pmask_teacher, Pbar_param, pmask_student, temp: float,
+                    chunk_p: int = 64) -> float:
+    """InfoNCE-distillation loss on the test queries (mainv2_iter_distill_infonce.py:324-344)."""
+    Psb = l2_normalize(Pbar_param * pmask_student.unsqueeze(-1))
+    if isinstance(teacher, TeacherScorer):
+        sc_t = teacher.scores(Q_test_norm, qmask_test)
+    else:
+        sc_t = score_multi_vector_masked(Q_test_norm, teacher, qmask_test, pmask_teacher, chunk_p=chunk_p)
+    sc_s = score_multi_vector_masked(Q_test_norm, Psb, qmask_test, pmask_student, chunk_p=chunk_p)
+    return float(infonce_distillation_loss(sc_s, sc_t, temperature=temp).item())
+
+
+def update_best(best: Optional[Dict[str, Any]], metrics: Dict[str, Any], step: int, kind: str) -> Tuple[Dict[str, Any], bool]:
+    """kind 'r1': Recall@1 then NDCG@5 as tie-break; 'nd5': the other way round."""
+    r1, nd5 = float(metrics["Recall"]["Recall@1"]), float(metrics["NDCG"]["NDCG@5"])
+    cur = {"step": step, "Recall@1": r1, "NDCG@5": nd5}
+    if best is None:
+        return cur, True
+    a, b = ("Recall@1", "NDCG@5") if kind == "r1" else ("NDCG@5", "Recall@1")
+    better = cur[a] > best[a] or (cur[a] == best[a] and cur[b] > best[b])
+    return (cur, True) if better else (best, False)
+
+
+def save_best_npz(*, out_dir: Path, fname: str, dataset: str, mf: int, step: int, best, metrics, Pbar_param,
+                  pmask_student, docid_tr, doc_attn_in, doc_img_in, args):
+    P_np = (Pbar_param.detach() * pmask_student.unsqueeze(-1)).cpu().numpy().astype(np.float32)
+    docs_obj = tokens_to_object(P_np, pmask_student.detach().cpu().numpy().astype(bool))
+    save_compressed_npz(
+        save_path=out_dir / fname, docid=_as_object_array(docid_tr), documents_obj=docs_obj,
+        doc_attnmask_obj=doc_attn_in, doc_imgmask_obj=doc_img_in,
+        meta={"dataset": dataset, "mf": mf, "step": int(step),
+              "best_type": "Recall@1" if fname == "best_recall.npz" else "NDCG@5", "best": best,
+              "eval": {"Recall@1": float(metrics["Recall"]["Recall@1"]), "NDCG@5": float(metrics["NDCG"]["NDCG@5"])},
+              "latency": float(metrics["latency"]), "loss": "infonce_distillation_loss", "temp": args.temp, "lr": args.lr})
+
+
+def log_eval(logger, tb, *, dataset: str, mf: int, step: int, metrics, loss: float):
+    if tb is not None:
+        tb.add_scalar("eval/Recall@1", float(metrics["Recall"]["Recall@1"]), step)
+        tb.add_scalar("eval/NDCG@5", float(metrics["NDCG"]["NDCG@5"]), step)
+        tb.add_scalar("eval/loss", float(loss), step)
+    log_json(logger, {"dataset": dataset, "mf": mf, "step": int(step), "eval/loss": float(loss),
+                      "eval/Recall@1": float(metrics["Recall"]["Recall@1"]),
+                      "eval/NDCG@5": float(metrics["NDCG"]["NDCG@5"]), "eval/latency": float(metrics["latency"])})
+
+
+def build_argparser():
+    p = argparse.ArgumentParser(description="InfoNCE distillation of compressed page embeddings (MI355X)")
+    p.add_argument("--datasets", type=str, nargs="+", required=True)
+    p.add_argument("--mapping_json", type=str, required=True,
+                   help="JSON {dataset: {pseudoQ, split_before, mf5, mf10, ...: npz filename}} (the reference's DATASETMAP)")
+    p.add_argument("--query_root", type=str, default=".")
+    p.add_argument("--teacher_root", type=str, default=".")
+    p.add_argument("--init_root", type=str, default=".")
+    p.add_argument("--mfs", type=int, nargs="+", default=[5, 10, 25, 50])
+    p.add_argument("--out_root", type=str, default="results")
+    p.add_argument("--name", type=str, default="infonce_distill train")
+    p.add_argument("--max_steps", type=int, default=23460)
+    p.add_argument("--eval_every", type=int, default=500)
+    p.add_argument("--q_batch", type=int, default=32)
+    p.add_argument("--opt", type=str, default="adamw")
+    p.add_argument("--lr", type=float, default=1e-3)
+    p.add_argument("--weight_decay", type=float, default=1e-2)
+    p.add_argument("--temp", type=float, default=0.1)
+    p.add_argument("--print_every", type=int, default=20)
+    p.add_argument("--device", type=str, default="auto")
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--cache_teacher_scores", action="store_true",
+                   help="keep the (n_train_queries, N) teacher score matrix on the device (result-identical)")
+    return p
+
+
+def run(args) -> None:
+    set_seed(args.seed)
+    device = torch.device("cuda" if args.device == "auto" else args.device)
+    mapping = json.loads(Path(args.mapping_json).read_text())
+    for dataset in args.datasets:
+        paths = mapping[dataset]
+        q_payload = load_query_payload(f"{args.query_root}/{paths['pseudoQ']}")
+        t_payload = load_payload(f"{args.teacher_root}/{paths['split_before']}")
+        docid_tr = t_payload["docid"]
+        Q_train, qmask_train = preprocess_queries(q_payload["query"], q_payload["query_attnmask"], device="cpu")
+        Q_train, qmask_train = Q_train.pin_memory(), qmask_train.pin_memory()
+        Q_test, qmask_test = preprocess_queries(t_payload["query"], t_payload["query_attnmask"], device=device)
+        P_t_raw, pmask_t, _ = preprocess_docs(t_payload["documents"], t_payload["doc_attnmask"], t_payload["doc_imgmask"], device)
+        P_t_norm = l2_normalize(P_t_raw * pmask_t.unsqueeze(-1)).detach()
+        n_pages = P_t_norm.shape[0]
+        n_train = Q_train.shape[0]
+        teacher = TeacherScorer(P_t_norm, pmask_t, cache_size=n_train if args.cache_teacher_scores else 0)
+        del P_t_raw
+        steps_per_epoch = (n_train + args.q_batch - 1) // args.q_batch
+        eval_every = max(int(args.eval_every if args.eval_every and args.eval_every > 0 else steps_per_epoch), 1)
+
+        for mf in args.mfs:
+            key = f"mf{mf}"
+            if key not in paths:
+                raise ValueError(f"Missing mapping for {dataset}:{key}")
+            init = load_init_payload(f"{args.init_root}/{paths[key]}")
+            Pbar_obj, attn_in, img_in = init["documents"], init["doc_attnmask"], init["doc_imgmask"]
+            if init.get("docid") is not None:
+                (Pbar_obj, attn_in, img_in), ok = align_by_docid(_as_object_array(docid_tr), _as_object_array(init["docid"]),
+                                                                 Pbar_obj, attn_in, img_in)
+                if ok:
+                    print(f"[align] {dataset} mf{mf}: init matched by docid")
+            Pbar_raw, pmask_s, _ = preprocess_docs(Pbar_obj, attn_in, img_in, device)
+            if Pbar_raw.shape[0] != n_pages:
+                raise ValueError(f"init doc count mismatch: got {Pbar_raw.shape[0]} vs teacher {n_pages}")
+            Pbar_param = nn.Parameter(Pbar_raw * pmask_s.unsqueeze(-1))
+            opt = set_optimizer(args.opt, Pbar_param, args.lr, args.weight_decay)
+            out_dir = Path(args.out_root) / args.name / f"mf{mf}" / dataset
+            out_dir.mkdir(parents=True, exist_ok=True)
+            logger, tb = get_logger(out_dir)
+            cfg = out_dir / "config.json"
+            if not cfg.exists():
+                cfg.write_text(json.dumps({"dataset": dataset, "mf": mf, **vars(args)}, ensure_ascii=False, indent=2))
+            evaluator = CustomRetrievalEvaluator()
+            ev_args = dict(evaluator=evaluator, Q_test_norm=Q_test, qmask_test=qmask_test, Pbar_param=Pbar_param,
+                           pmask_student=pmask_s, relevant_docs_test=t_payload["relevant_docs"],
+                           docidx_2_docid_test=t_payload["docidx_2_docid"], qsidx_2_query_test=t_payload["qsidx_2_query"])
+            el_args = dict(Q_test_norm=Q_test, qmask_test=qmask_test, teacher=teacher, pmask_teacher=pmask_t,
+                           Pbar_param=Pbar_param, pmask_student=pmask_s, temp=args.temp)
+            metrics = eval_retrieval(**ev_args)
+            log_eval(logger, tb, dataset=dataset, mf=mf, step=0, metrics=metrics, loss=evaluation_loss(**el_args))
+            log_json(logger, {"dataset": dataset, "mf": mf, "step": 0, "note": "init Pbar before training"})
+            best_r1, _ = update_best(None, metrics, 0, "r1")
+            best_nd5, _ = update_best(None, metrics, 0, "nd5")
+            last = metrics
+
+            gen = torch.Generator().manual_seed(args.seed)
+            perm, cursor = torch.randperm(n_train, generator=gen), 0
+            t0, loss_sum, loss_cnt = time.time(), 0.0, 0
+            for step in range(1, args.max_steps + 1):
+                if cursor >= n_train:                               # epoch boundary: reshuffle (DataLoader(shuffle=True))
+                    perm, cursor = torch.randperm(n_train, generator=gen), 0
+                idx = perm[cursor:cursor + args.q_batch]
+                cursor += args.q_batch
+                loss_val = train_one_step(Q_train[idx], qmask_train[idx], teacher, pmask_t, Pbar_param, pmask_s, opt,
+                                          temp=args.temp, qidx=idx if args.cache_teacher_scores else None)
+                loss_sum += loss_val
+                loss_cnt += 1
+                if tb is not None:
+                    tb.add_scalar("train/loss", float(loss_val), step)
+                if args.print_every and step % args.print_every == 0:
+                    log_json(logger, {"dataset": dataset, "mf": mf, "step": step, "train/loss": float(loss_val),
+                                      "train/avg_loss": float(loss_sum / max(loss_cnt, 1)), "time_sec": float(time.time() - t0)})
+                if step % eval_every == 0 or step == args.max_steps:
+                    metrics = eval_retrieval(**ev_args)
+                    log_eval(logger, tb, dataset=dataset, mf=mf, step=step, metrics=metrics, loss=evaluation_loss(**el_args))
+                    last = metrics
+                    best_r1, upd_r1 = update_best(best_r1, metrics, step, "r1")
+                    best_nd5, upd_nd5 = update_best(best_nd5, metrics, step, "nd5")
+                    for upd, best, fname, tag in ((upd_r1, best_r1, "best_recall.npz", "best recall"),
+                                                  (upd_nd5, best_nd5, "best_ndcg5.npz", "best nDCG@5")):
+                        if upd:
+                            logger.info(f"{tag} step| {step} | nDCG@5={best['NDCG@5']:.5f} | Recall@1={best['Recall@1']:.5f} "
+                                        f"| Latency {metrics['latency']:.5f}")
+                            save_best_npz(out_dir=out_dir, fname=fname, dataset=dataset, mf=mf, step=step, best=best,
+                                          metrics=metrics, Pbar_param=Pbar_param, pmask_student=pmask_s, docid_tr=docid_tr,
+                                          doc_attn_in=attn_in, doc_img_in=img_in, args=args)
+            log_json(logger, {"summary/latency": float(last.get("latency", 0.0)), "summary/best_recall": best_r1,
+                              "summary/best_ndcg5": best_nd5, "note": "training finished"})
+            print(f"[done] {dataset} mf{mf} -> {out_dir}")
+            if tb is not None:
+                tb.flush()
+                tb.close()
+
+
+def main(argv=None):
+    run(build_argparser().parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()

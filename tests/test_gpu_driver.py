@@ -1,0 +1,121 @@
+"""End-to-end: synthetic feature dumps in the reference's npz schema -> the driver (train + eval + logging +
+checkpoint), checked against the log / directory contract that the reference's summary_results.py consumes, and
+one driver step against the oracle's restatement of train_one_step."""
+import json
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maxsim_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _obj(items):
+    a = np.empty(len(items), dtype=object)
+    for i, v in enumerate(items):
+        a[i] = v
+    return a
+
+
+def write_synthetic_dataset(root, n_pages=48, lt=96, mf=4, n_train=192, seed=0):
+    rng = np.random.default_rng(seed)
+    d = 128
+    lens = rng.integers(lt - 20, lt + 1, size=n_pages)
+    docs = [rng.normal(size=(l, d)).astype(np.float32) for l in lens]
+    docid = _obj([f"page_{i:03d}" for i in range(n_pages)])
+    attn = _obj([np.ones(l, dtype=bool) for l in lens])
+    img = _obj([np.concatenate([np.zeros(3, bool), np.ones(l - 3, bool)]) for l in lens])     # 3 text-prefix tokens
+
+    def make_queries(n, targets):
+        qs = []
+        for t in targets:
+            rows = rng.choice(np.arange(3, lens[t]), size=12, replace=False)
+            base = docs[t][rows] / np.linalg.norm(docs[t][rows], axis=1, keepdims=True)
+            qs.append((base + 3.0 * rng.normal(size=base.shape) / np.sqrt(d)).astype(np.float32))
+        return _obj(qs), _obj([np.ones(12, dtype=bool) for _ in range(n)])
+
+    test_targets = rng.permutation(n_pages)
+    q_test, qa_test = make_queries(n_pages, test_targets)
+    qid_test = _obj([f"q{i}" for i in range(n_pages)])
+    np.savez_compressed(
+        root / "synth_dump_all.npz", task=np.array("synthetic"), model=np.array("none"), documents=_obj(docs),
+        doc_attnmask=attn, doc_imgmask=img, query=q_test, query_attnmask=qa_test, docid=docid, qid=qid_test,
+        relevant_docs=np.array({f"q{i}": {str(docid[t]): 1} for i, t in enumerate(test_targets)}, dtype=object),
+        docidx_2_docid=np.array({str(i): str(docid[i]) for i in range(n_pages)}, dtype=object), qsidx_2_query=qid_test)
+    train_targets = rng.integers(0, n_pages, size=n_train)
+    q_tr, qa_tr = make_queries(n_train, train_targets)
+    np.savez_compressed(root / "synth_query.npz", query=q_tr, qid=_obj([f"pq{i}" for i in range(n_train)]), query_attnmask=qa_tr)
+    # student init: block means of the teacher pages, stored in a PERMUTED docid order (exercises align_by_docid)
+    perm = rng.permutation(n_pages)
+    init_docs, init_attn, init_img = [], [], []
+    for i in perm:
+        ls = int(np.ceil(lens[i] / mf))
+        pad = np.zeros((ls * mf, d), np.float32)
+        pad[: lens[i]] = docs[i] * img[i][:, None]
+        init_docs.append(pad.reshape(ls, mf, d).mean(1).astype(np.float32))
+        init_attn.append(np.ones(ls, bool))
+        init_img.append(np.ones(ls, bool))
+    (root / "mf4").mkdir()
+    np.savez_compressed(root / "mf4" / "synth.npz", docid=docid[perm], documents=_obj(init_docs),
+                        doc_attnmask=_obj(init_attn), doc_imgmask=_obj(init_img))
+    (root / "map.json").write_text(json.dumps({"synth": {"pseudoQ": "synth_query.npz", "split_before": "synth_dump_all.npz",
+                                                          "mf4": "mf4/synth.npz"}}))
+
+
+def test_driver_end_to_end(tmp_path):
+    import evdr_amd  # noqa: F401
+    from evdr_amd import driver
+    from evdr_amd.utils.preprocess_data import load_init_payload, load_npz
+    write_synthetic_dataset(tmp_path)
+    out = tmp_path / "results"
+    driver.main(["--datasets", "synth", "--mapping_json", str(tmp_path / "map.json"), "--query_root", str(tmp_path),
+                 "--teacher_root", str(tmp_path), "--init_root", str(tmp_path), "--mfs", "4", "--out_root", str(out),
+                 "--name", "infonce_distill", "--max_steps", "60", "--eval_every", "20", "--print_every", "10",
+                 "--q_batch", "32", "--lr", "3e-3", "--cache_teacher_scores"])
+    run_dir = out / "infonce_distill" / "mf4" / "synth"          # <root>/<setting>/mf<k>/<dataset>/train.log
+    lines = (run_dir / "train.log").read_text().strip().splitlines()
+    assert all(re.match(r"^\[[^\]]+\]\[INFO\] ", ln) for ln in lines)
+    # the exact regex of the reference's summary_results.py:35
+    m = re.search(r"(\{.*\"summary\/best_ndcg5\".*\})\s*$", lines[-1])
+    summary = json.loads(m.group(1))
+    best = summary["summary/best_ndcg5"]
+    assert set(best) == {"step", "Recall@1", "NDCG@5"} and 0.0 <= best["NDCG@5"] <= 1.0
+    evals = [json.loads(ln[ln.index("{"):]) for ln in lines if '"eval/NDCG@5"' in ln]
+    assert [e["step"] for e in evals] == [0, 20, 40, 60]
+    assert best["NDCG@5"] >= evals[0]["eval/NDCG@5"] and all(np.isfinite(e["eval/loss"]) for e in evals)
+    trains = [json.loads(ln[ln.index("{"):]) for ln in lines if '"train/loss"' in ln]
+    assert len(trains) == 6 and all(np.isfinite(t["train/loss"]) for t in trains)
+    assert trains[-1]["train/avg_loss"] < trains[0]["train/avg_loss"]     # the student fits the teacher's top-1 labels
+    cfg = json.loads((run_dir / "config.json").read_text())
+    assert cfg["dataset"] == "synth" and cfg["mf"] == 4 and cfg["temp"] == 0.1
+    ck = load_init_payload(str(run_dir / "best_ndcg5.npz"))
+    assert len(ck["documents"]) == 48 and ck["documents"][0].shape[1] == 128
+    assert [str(x) for x in ck["docid"]] == [f"page_{i:03d}" for i in range(48)]      # teacher order, not the init's
+    meta = load_npz(str(run_dir / "best_ndcg5.npz"))["meta"].item()
+    assert meta["best_type"] == "NDCG@5" and meta["loss"] == "infonce_distillation_loss"
+
+
+def test_driver_step_matches_oracle():
+    """driver.train_one_step with the resident TeacherScorer == the oracle's restatement of the reference step."""
+    import evdr_amd  # noqa: F401
+    import golden_recipes as R
+    from evdr_amd import driver
+    dev = torch.device("cuda:0")
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = R.train_case("b4n8")
+    Ptn = O.l2_normalize(Pt * pmt.unsqueeze(-1))
+    loss_o, grad_o, after_o, sc_t_o, _ = O.distill_train_step(Qb, qmb, Ptn, pmt, Pbar0 * pms.unsqueeze(-1), pms,
+                                                             hp["temp"], hp["lr"], hp["wd"])
+    teacher = driver.TeacherScorer(Ptn.to(dev), pmt.to(dev), cache_size=16)
+    param = torch.nn.Parameter((Pbar0 * pms.unsqueeze(-1)).to(dev))
+    opt = torch.optim.AdamW([param], lr=hp["lr"], weight_decay=hp["wd"])
+    qidx = torch.tensor([3, 7, 1, 12])
+    loss = driver.train_one_step(Qb, qmb, teacher, pmt.to(dev), param, pms.to(dev), opt, temp=hp["temp"], qidx=qidx)
+    np.testing.assert_allclose(loss, loss_o, rtol=1e-5)
+    np.testing.assert_allclose(param.detach().cpu().numpy(), after_o.numpy(), atol=1e-6)
+    np.testing.assert_allclose(teacher.cache[qidx.to(dev)].cpu().numpy(), sc_t_o.numpy(), atol=1e-4)
+    # second visit of the same queries is served from the cache (no recomputation needed, same result)
+    again = teacher.scores(Qb.to(dev), qmb.to(dev), qidx)
+    assert torch.equal(again, teacher.cache[qidx.to(dev)])
