@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Secondary benchmark (BASELINE.json configs[4]): one InfoNCE-distillation step at the docvqa_test_subsampled
+shape -- 32 queries x 32 tokens, N = 500 pages, teacher 1030 patches, student 206 patches (mf5), fp32 parameters,
+temperature 0.1, AdamW(lr 1e-3, wd 1e-2).  Reports ms/step of the drop-in functions used exactly like
+mainv2_iter_distill_infonce.py:269-292 ("call_pattern"), of the driver's resident-teacher step ("resident") and of
+the same with cached teacher scores ("cached"); `--eager` adds a plain torch restatement of the reference's four
+ATen ops on the same GPU for context.  Not the driver's headline bench (that is bench.py)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def eager_maxsim(Q, P, qmask, pmask, chunk_p=64):
+    """The reference's op sequence (evaluator/retrieval.py:187-211) in plain torch, for timing on the GPU only."""
+    out = []
+    qf = qmask.float()
+    for s in range(0, P.shape[0], chunk_p):
+        Pc, mc = P[s:s + chunk_p], pmask[s:s + chunk_p]
+        sim = torch.einsum("qnd,cmd->qcnm", Q, Pc).masked_fill(~mc[None, :, None, :], -1e4)
+        mx = sim.max(dim=-1).values * mc.any(dim=1)[None, :, None].float() * qf[:, None, :]
+        out.append(mx.sum(dim=-1))
+    return torch.cat(out, dim=1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pages", type=int, default=500)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--eager", action="store_true")
+    a = ap.parse_args()
+    import evdr_amd  # noqa: F401
+    from evdr_amd import driver
+    from evdr_amd.criterion import infonce_distillation_loss
+    from evdr_amd.evaluator.retrieval import score_multi_vector_masked
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(20261004)
+    N, B, Lt, Ls, Lq, D = a.pages, a.batch, 1030, 206, 32, 128
+    Pt = l2_normalize(torch.randn((N, Lt, D), generator=g, device=dev))
+    pmt = torch.ones((N, Lt), dtype=torch.bool, device=dev)
+    pms = torch.ones((N, Ls), dtype=torch.bool, device=dev)
+    Pbar0 = Pt[:, : Ls * 5].reshape(N, Ls, 5, D).mean(2) + 0.05 * torch.randn((N, Ls, D), generator=g, device=dev)
+    Qall = l2_normalize(torch.randn((64 * B, Lq, D), generator=g, device=dev))
+    qmall = torch.ones((64 * B, Lq), dtype=torch.bool, device=dev)
+
+    def run(kind):
+        param = torch.nn.Parameter(Pbar0.clone())
+        opt = torch.optim.AdamW([param], lr=1e-3, weight_decay=1e-2)
+        teacher = driver.TeacherScorer(Pt, pmt, cache_size=Qall.shape[0] if kind == "cached" else 0) if kind != "call_pattern" and kind != "eager" else None
+
+        def step(i):
+            idx = torch.arange(B) + (i % 64) * B
+            Qb, qmb = Qall[idx], qmall[idx]
+            if kind in ("resident", "cached"):
+                return driver.train_one_step(Qb, qmb, teacher, pmt, param, pms, opt, temp=0.1, qidx=idx if kind == "cached" else None)
+            score = eager_maxsim if kind == "eager" else score_multi_vector_masked
+            Psb = l2_normalize(param * pms.unsqueeze(-1))
+            with torch.no_grad():
+                sc_t = score(Qb, Pt, qmb, pmt, 64)
+            sc_s = score(Qb, Psb, qmb, pms, 64)
+            if kind == "eager":
+                loss = torch.nn.functional.cross_entropy(sc_s / 0.1, sc_t.argmax(dim=1))
+            else:
+                loss = infonce_distillation_loss(sc_s, sc_t, temperature=0.1)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            return float(loss.item())
+
+        if kind == "cached":
+            for i in range(64):
+                step(i)                                   # fill the teacher-score cache (one epoch)
+        for i in range(a.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            last = step(i)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / a.steps, last
+
+    res = {}
+    for kind in ["call_pattern", "resident", "cached"] + (["eager"] if a.eager else []):
+        ms, loss = run(kind)
+        res[kind] = {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "last_loss": loss}
+    print(json.dumps({"metric": "InfoNCE-distillation step time", "unit": "ms/step", "higher_is_better": False,
+                      "config": {"workload": "mainv2_iter_distill_infonce step (BASELINE.json configs[4])", "pages": N,
+                                 "batch_queries": B, "teacher_patches": Lt, "student_patches": Ls, "dtype": "fp32 (bf16x3 split MFMA)"},
+                      "results": res}))
+
+
+if __name__ == "__main__":
+    main()

@@ -175,6 +175,26 @@ int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const 
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd launch");
 }
 
+int evdr_l2norm_fwd(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps, float* y,
+                    float* norm_or_null, void* hip_stream) {
+    if (rows < 0) return fail(EVDR_ERR_ARG, "negative rows");
+    if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported", (long long)d);
+    if (rows == 0) return EVDR_OK;
+    if (!x || !y) return fail(EVDR_ERR_ARG, "evdr_l2norm_fwd: null pointer");
+    hipError_t e = evdr_launch_l2norm_fwd(x, rowmask_or_null, rows, eps, y, norm_or_null, (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "l2norm_fwd launch");
+}
+
+int evdr_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask_or_null, const float* norm, int64_t rows,
+                    int64_t d, float eps, float* dx, void* hip_stream) {
+    if (rows < 0) return fail(EVDR_ERR_ARG, "negative rows");
+    if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported", (long long)d);
+    if (rows == 0) return EVDR_OK;
+    if (!gy || !x || !norm || !dx) return fail(EVDR_ERR_ARG, "evdr_l2norm_bwd: null pointer");
+    hipError_t e = evdr_launch_l2norm_bwd(gy, x, rowmask_or_null, norm, rows, eps, dx, (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "l2norm_bwd launch");
+}
+
 int evdr_topk(const float* scores, const int32_t* idx_map_or_null, int64_t nq, int64_t n, int64_t row_stride,
               int32_t idx_base, int k, float* top_scores, int32_t* top_idx, void* hip_stream) {
     if (nq < 0 || n < 0) return fail(EVDR_ERR_ARG, "negative size");

@@ -9,23 +9,40 @@
 
 namespace {
 
-constexpr int BW_THREADS = 256;
-constexpr int BW_ROWS = 128;          // patch rows of dP accumulated per workgroup: 64 KiB of LDS
+constexpr int BW_THREADS = 512;
+constexpr int BW_ROWS_MAX = 256;      // patch rows of dP owned by one workgroup: 128 KiB of LDS (fp32 x 128)
 
+// One workgroup owns BW_ROWS consecutive patch rows of one page.  fp32 LDS atomics are NOT used: ds_add_f32 costs
+// ~175 cycles per wave-instruction on gfx950 (measured: 346 us with them, 28 us with plain read-modify-write on this
+// very kernel).  Instead the (query, token) pairs are bucketed by target row -- integer histogram, exclusive scan,
+// scatter: three small LDS passes per chunk of pairs -- and each 16-lane group then OWNS whole rows: it walks a row's
+// bucket with four 512-B query-row loads in flight, accumulates in registers and adds into the slab with plain LDS
+// accesses.  Every dP element is written to HBM exactly once; masked rows come out as exact zeros.
+// The order of the additions inside one row follows the scatter order (not fixed run to run, like index_add_ on a GPU).
+template <int BW_ROWS, int CHUNK>
 __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __restrict__ g,
                                                                const float* __restrict__ Q,
                                                                const uint8_t* __restrict__ qmask,
                                                                const uint8_t* __restrict__ pmask,
                                                                const uint16_t* __restrict__ argmax,
                                                                float* __restrict__ dP, int nq, int lq, int np, int lp) {
-    __shared__ __attribute__((aligned(16))) float acc[BW_ROWS * EVDR_D];
+    constexpr int PER_THREAD = CHUNK / BW_THREADS;
+    constexpr int NGROUPS = BW_THREADS / 16;
+    extern __shared__ __attribute__((aligned(16))) float acc[];          // [BW_ROWS][128]
+    int* list = reinterpret_cast<int*>(acc + BW_ROWS * EVDR_D);          // [CHUNK] pair index inside the chunk, bucketed
+    float* wl = reinterpret_cast<float*>(list + CHUNK);                  // [CHUNK] weight of list[k]
+    int* hist = reinterpret_cast<int*>(wl + CHUNK);                      // [BW_ROWS] bucket sizes
+    int* offs = hist + BW_ROWS;                                          // [BW_ROWS] bucket starts
+    int* cur = offs + BW_ROWS;                                           // [BW_ROWS] scatter cursors
     __shared__ int sh_has;
     const int page = blockIdx.x;
     const int r0 = blockIdx.y * BW_ROWS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = min(BW_ROWS, lp - r0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int gid = tid >> 4, sub = tid & 15;
 
     if (tid == 0) sh_has = (pmask == nullptr) ? 1 : 0;
-    for (int i = tid; i < BW_ROWS * EVDR_D / 4; i += BW_THREADS) reinterpret_cast<f32x4*>(acc)[i] = f32x4{0, 0, 0, 0};
+    for (int i = tid; i < rows * (EVDR_D / 4); i += BW_THREADS) reinterpret_cast<f32x4*>(acc)[i] = f32x4{0, 0, 0, 0};
     __syncthreads();
     if (pmask != nullptr) {                               // has(p) = any(pmask[p])  (retrieval.py:192)
         int any = 0;
@@ -35,22 +52,131 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
     __syncthreads();
     if (sh_has) {
         const int npairs = nq * lq;
-        for (int i = wave; i < npairs; i += BW_THREADS / 64) {
-            const int q = i / lq, n = i - q * lq;
-            const int a = (int)argmax[((int64_t)q * np + page) * lq + n] - r0;
-            if (a < 0 || a >= BW_ROWS) continue;          // wave-uniform
-            if (qmask != nullptr && qmask[i] == 0) continue;
-            const float w = g[(int64_t)q * np + page];
-            if (w == 0.f) continue;
-            const float2 qv = *reinterpret_cast<const float2*>(Q + (int64_t)i * EVDR_D + lane * 2);
-            atomicAdd(&acc[a * EVDR_D + lane * 2], w * qv.x);
-            atomicAdd(&acc[a * EVDR_D + lane * 2 + 1], w * qv.y);
+        for (int c0 = 0; c0 < npairs; c0 += CHUNK) {
+            for (int r = tid; r < BW_ROWS; r += BW_THREADS) { hist[r] = 0; cur[r] = 0; }
+            __syncthreads();
+            // (1) this thread's pairs: target row inside the slab (or -1) and weight g * qmask; bucket sizes
+            int a_loc[PER_THREAD];
+            float w_loc[PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < PER_THREAD; ++k) {
+                const int i = c0 + k * BW_THREADS + tid;
+                int a = -1;
+                float w = 0.f;
+                if (i < npairs) {
+                    const int q = i / lq, n = i - q * lq;
+                    a = (int)argmax[((int64_t)q * np + page) * lq + n] - r0;
+                    w = g[(int64_t)q * np + page];
+                    if (qmask != nullptr && qmask[i] == 0) w = 0.f;
+                    if (a < 0 || a >= rows || w == 0.f) a = -1;
+                }
+                a_loc[k] = a;
+                w_loc[k] = w;
+                if (a >= 0) atomicAdd(&hist[a], 1);
+            }
+            __syncthreads();
+            // (2) exclusive scan of the bucket sizes (BW_ROWS <= BW_THREADS: one element per thread, Hillis-Steele)
+            int v = (tid < BW_ROWS) ? hist[tid] : 0;
+            if (tid < BW_ROWS) offs[tid] = v;
+            __syncthreads();
+            for (int o = 1; o < BW_ROWS; o <<= 1) {
+                int add = (tid < BW_ROWS && tid >= o) ? offs[tid - o] : 0;
+                __syncthreads();
+                if (tid < BW_ROWS) offs[tid] += add;
+                __syncthreads();
+            }
+            if (tid < BW_ROWS) offs[tid] -= v;            // inclusive -> exclusive
+            __syncthreads();
+            // (3) scatter the pairs into their buckets
+#pragma unroll
+            for (int k = 0; k < PER_THREAD; ++k) {
+                const int a = a_loc[k];
+                if (a >= 0) {
+                    const int slot = offs[a] + atomicAdd(&cur[a], 1);
+                    list[slot] = k * BW_THREADS + tid;
+                    wl[slot] = w_loc[k];
+                }
+            }
+            __syncthreads();
+            // (4) each 16-lane group owns rows gid, gid + NGROUPS, ...: registers accumulate, 4 row loads in flight
+            for (int r = gid; r < rows; r += NGROUPS) {
+                const int n = hist[r], o = offs[r];
+                if (n == 0) continue;
+                f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+                for (int k = 0; k < n; k += 4) {
+                    f32x4 v0[4], v1[4];
+                    float w4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int kk = min(k + u, n - 1);
+                        const float* qrow = Q + (int64_t)(c0 + list[o + kk]) * EVDR_D + sub * 8;
+                        w4[u] = (k + u < n) ? wl[o + kk] : 0.f;
+                        v0[u] = *reinterpret_cast<const f32x4*>(qrow);
+                        v1[u] = *reinterpret_cast<const f32x4*>(qrow + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        s0 += v0[u] * w4[u];
+                        s1 += v1[u] * w4[u];
+                    }
+                }
+                f32x4* dst = reinterpret_cast<f32x4*>(acc + r * EVDR_D + sub * 8);
+                dst[0] += s0;
+                dst[1] += s1;
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
-    const int rows = min(BW_ROWS, lp - r0);
     f32x4* out = reinterpret_cast<f32x4*>(dP + ((int64_t)page * lp + r0) * EVDR_D);
-    for (int i = tid; i < rows * EVDR_D / 4; i += BW_THREADS) out[i] = reinterpret_cast<const f32x4*>(acc)[i];
+    for (int i = tid; i < rows * (EVDR_D / 4); i += BW_THREADS) out[i] = reinterpret_cast<const f32x4*>(acc)[i];
+    (void)lane;
+}
+
+// ---- l2_normalize (utils/preprocess_data.py:8-9) with an optional per-row mask, forward and backward ---------------
+// y = m * x / (||m*x|| + eps);  one 16-lane group per 128-wide row (8 floats per lane, two 16-B accesses).
+// backward of y = x/(n + eps):  dx = g/(n+eps) - x * (x.g) / (n (n+eps)^2)   (n > 0; the norm's subgradient at 0 is 0)
+__global__ void __launch_bounds__(256) l2norm_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ rowmask,
+                                                        int64_t rows, float eps, float* __restrict__ y,
+                                                        float* __restrict__ norm) {
+    const int sub = threadIdx.x & 15;
+    for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < rows; r += (int64_t)gridDim.x * 16) {
+        const float m = (rowmask == nullptr || rowmask[r] != 0) ? 1.f : 0.f;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(x + r * EVDR_D + sub * 8);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(x + r * EVDR_D + sub * 8 + 4);
+        v0 *= m;
+        v1 *= m;
+        float ss = v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3] + v1[0] * v1[0] + v1[1] * v1[1] +
+                   v1[2] * v1[2] + v1[3] * v1[3];
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const float n = sqrtf(ss);
+        const float inv = 1.f / (n + eps);
+        *reinterpret_cast<f32x4*>(y + r * EVDR_D + sub * 8) = v0 * inv;
+        *reinterpret_cast<f32x4*>(y + r * EVDR_D + sub * 8 + 4) = v1 * inv;
+        if (sub == 0 && norm != nullptr) norm[r] = n;
+    }
+}
+
+__global__ void __launch_bounds__(256) l2norm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                        const uint8_t* __restrict__ rowmask, const float* __restrict__ norm,
+                                                        int64_t rows, float eps, float* __restrict__ dx) {
+    const int sub = threadIdx.x & 15;
+    for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < rows; r += (int64_t)gridDim.x * 16) {
+        const float m = (rowmask == nullptr || rowmask[r] != 0) ? 1.f : 0.f;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(x + r * EVDR_D + sub * 8);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(x + r * EVDR_D + sub * 8 + 4);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gy + r * EVDR_D + sub * 8);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gy + r * EVDR_D + sub * 8 + 4);
+        v0 *= m;
+        v1 *= m;
+        float dot = v0[0] * g0[0] + v0[1] * g0[1] + v0[2] * g0[2] + v0[3] * g0[3] + v1[0] * g1[0] + v1[1] * g1[1] +
+                    v1[2] * g1[2] + v1[3] * g1[3];
+        for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        const float n = norm[r];
+        const float inv = 1.f / (n + eps);
+        const float c = (n > 0.f) ? dot * inv * inv / n : 0.f;
+        *reinterpret_cast<f32x4*>(dx + r * EVDR_D + sub * 8) = (g0 * inv - v0 * c) * m;
+        *reinterpret_cast<f32x4*>(dx + r * EVDR_D + sub * 8 + 4) = (g1 * inv - v1 * c) * m;
+    }
 }
 
 // ---- infonce_distillation_loss (criterion.py:56-68) and d loss / d score_s, one workgroup per query row
@@ -125,13 +251,49 @@ __global__ void __launch_bounds__(256) mean_kernel(const float* __restrict__ x, 
 
 }  // namespace
 
+template <int BW_ROWS, int CHUNK>
+static hipError_t launch_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
+                             float* dP, int64_t nq, int64_t lq, int64_t np, int64_t lp, hipStream_t stream) {
+    constexpr int LDS = BW_ROWS * EVDR_D * 4 + CHUNK * 8 + BW_ROWS * 12;
+    auto kern = maxsim_bwd_kernel<BW_ROWS, CHUNK>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    dim3 grid((unsigned)np, (unsigned)((lp + BW_ROWS - 1) / BW_ROWS));
+    hipLaunchKernelGGL(kern, grid, dim3(BW_THREADS), LDS, stream, g, Q, qmask, pmask, argmax, dP, (int)nq, (int)lq, (int)np,
+                       (int)lp);
+    return hipGetLastError();
+}
+
 hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                   const uint16_t* argmax, float* dP, int64_t nq, int64_t lq, int64_t np, int64_t lp,
                                   hipStream_t stream) {
     if (np == 0 || lp == 0) return hipSuccess;
-    dim3 grid((unsigned)np, (unsigned)((lp + BW_ROWS - 1) / BW_ROWS));
-    hipLaunchKernelGGL(maxsim_bwd_kernel, grid, dim3(BW_THREADS), 0, stream, g, Q, qmask, pmask, argmax, dP, (int)nq,
-                       (int)lq, (int)np, (int)lp);
+    // a whole compressed page (the mf >= 5 students: <= 256 patches) is one slab, so every pair is bucketed once;
+    // longer pages are cut into 128-row slabs (two workgroups per CU)
+    if (lp <= 128) return launch_bwd<128, 1024>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, stream);
+    if (lp <= BW_ROWS_MAX) return launch_bwd<BW_ROWS_MAX, 2048>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, stream);
+    return launch_bwd<128, 1024>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, stream);
+}
+
+hipError_t evdr_launch_l2norm_fwd(const float* x, const uint8_t* rowmask, int64_t rows, float eps, float* y, float* norm,
+                                  hipStream_t stream) {
+    if (rows == 0) return hipSuccess;
+    int64_t blocks = (rows + 15) / 16;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, rowmask, rows, eps, y, norm);
+    return hipGetLastError();
+}
+
+hipError_t evdr_launch_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask, const float* norm, int64_t rows,
+                                  float eps, float* dx, hipStream_t stream) {
+    if (rows == 0) return hipSuccess;
+    int64_t blocks = (rows + 15) / 16;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, gy, x, rowmask, norm, rows, eps, dx);
     return hipGetLastError();
 }
 

@@ -32,7 +32,7 @@ from .criterion import infonce_distillation_loss
 from .evaluator.metrics import results_from_topk
 from .evaluator.retrieval import CustomRetrievalEvaluator, score_multi_vector_masked
 from .utils.preprocess_data import (_as_object_array, l2_normalize, load_init_payload, load_payload,
-                                    load_query_payload, preprocess_docs, preprocess_queries)
+                                    load_query_payload, normalize_masked, preprocess_docs, preprocess_queries)
 from .utils.utils import align_by_docid, get_logger, log_json, save_compressed_npz, set_optimizer, set_seed, tokens_to_object
 
 
@@ -66,7 +66,7 @@ def train_one_step(Qb, qmb, teacher, pmask_teacher, Pbar_param, pmask_student, o
     device = Pbar_param.device
     Qb = Qb.to(device, non_blocking=True)
     qmb = qmb.to(device, non_blocking=True)
-    Psb = l2_normalize(Pbar_param * pmask_student.unsqueeze(-1))
+    Psb = normalize_masked(Pbar_param, pmask_student)          # == l2_normalize(Pbar_param * pmask[..., None]), fused
     if isinstance(teacher, TeacherScorer):
         sc_t = teacher.scores(Qb, qmb, qidx)
     else:

@@ -168,3 +168,34 @@ def infonce_distill(score_s: torch.Tensor, score_t: torch.Tensor, temperature: f
         L.check(lib.evdr_infonce_distill_fwd_bwd(L.ptr(ss), L.ptr(st), b, n, float(temperature), L.ptr(loss),
                                                  L.ptr(grad), L.ptr(row), L.current_stream_handle(dev)))
     return loss, grad
+
+
+def l2norm_forward(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A4 fused with the row mask: y = m*x / (||m*x|| + eps) over the last (128-wide) dim; returns (y, norms)."""
+    dev = _require_cuda(x)
+    if x.shape[-1] != D or x.dtype != torch.float32:
+        raise RuntimeError("l2norm kernel needs fp32 rows of width 128")
+    lib = L.load()
+    xc = x.contiguous()
+    rows = xc.numel() // D
+    y = torch.empty_like(xc)
+    norm = torch.empty(xc.shape[:-1], dtype=torch.float32, device=dev)
+    m = _mask_u8(rowmask, xc.shape[:-1], dev)
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_l2norm_fwd(L.ptr(xc), L.ptr(m), rows, D, float(eps), L.ptr(y), L.ptr(norm),
+                                    L.current_stream_handle(dev)))
+    return y, norm
+
+
+def l2norm_backward(gy: torch.Tensor, x: torch.Tensor, rowmask: Optional[torch.Tensor], norm: torch.Tensor,
+                    eps: float) -> torch.Tensor:
+    dev = _require_cuda(gy, x, norm)
+    lib = L.load()
+    gc, xc = gy.float().contiguous(), x.contiguous()
+    rows = xc.numel() // D
+    dx = torch.empty_like(xc)
+    m = _mask_u8(rowmask, xc.shape[:-1], dev)
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_l2norm_bwd(L.ptr(gc), L.ptr(xc), L.ptr(m), L.ptr(norm), rows, D, float(eps), L.ptr(dx),
+                                    L.current_stream_handle(dev)))
+    return dx

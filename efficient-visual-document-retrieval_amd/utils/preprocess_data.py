@@ -19,11 +19,46 @@ def load_npz(path: str):
     return np.load(path, allow_pickle=True)
 
 
+class _L2NormMasked(torch.autograd.Function):
+    """y = m * x / (||m * x|| + eps) on the HIP kernels (evdr_l2norm_fwd / _bwd); m = optional per-row mask."""
+
+    @staticmethod
+    def forward(ctx, x, rowmask, eps):
+        from .. import ops
+        y, norm = ops.l2norm_forward(x, rowmask, eps)
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(x, rowmask, norm)
+            ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import ops
+        x, rowmask, norm = ctx.saved_tensors
+        return ops.l2norm_backward(gy, x, rowmask, norm, ctx.eps), None, None
+
+
+def _kernel_ok(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.shape[-1] == 128 and x.numel() > 0
+
+
 def l2_normalize(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     """x / (||x||_2 + eps) over the last dim -- eps is ADDED to the norm, zero rows stay exactly zero and get
     the subgradient 0 through the norm (utils/preprocess_data.py:8-9; applied to Pbar*pmask every step,
-    mainv2_iter_distill_infonce.py:279)."""
+    mainv2_iter_distill_infonce.py:279).  fp32 CUDA tensors of width 128 (the page / query embeddings of the
+    training step) run on one fused HIP kernel each way; anything else (host-side preprocessing on the CPU, other
+    widths) is the same formula in torch."""
+    if _kernel_ok(x):
+        return _L2NormMasked.apply(x, None, float(eps))
     return x / (torch.linalg.vector_norm(x, ord=2, dim=-1, keepdim=True) + eps)
+
+
+def normalize_masked(x: torch.Tensor, rowmask: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """l2_normalize(x * rowmask[..., None]) in ONE kernel each way (the `Pbar_param * pmask` multiply of
+    mainv2_iter_distill_infonce.py:279 fused into the normalisation); same values and gradients."""
+    if _kernel_ok(x):
+        return _L2NormMasked.apply(x, rowmask, float(eps))
+    return l2_normalize(x * rowmask.unsqueeze(-1).to(x.dtype), eps)
 
 
 def parse_relevant_docs(z) -> Dict[str, dict]:

@@ -93,6 +93,17 @@ int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const 
                     const uint16_t* argmax, float* dP,
                     int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d, void* hip_stream);
 
+/* ---- A4: l2_normalize (utils/preprocess_data.py:8-9) fused with the page mask, forward and backward -----------------
+ * y[r,:] = m_r * x[r,:] / (||m_r * x[r,:]||_2 + eps), m_r = rowmask[r] != 0 (NULL = all ones); rows x 128 fp32.
+ * norm_or_null receives ||m_r x_r|| (needed by the backward).  One call replaces the `Pbar * pmask` multiply and
+ * the four ATen kernels of l2_normalize on the training step (mainv2_iter_distill_infonce.py:279).
+ * Backward: dx = m * ( gy/(n+eps) - (m x) * ((m x).gy) / (n (n+eps)^2) ), with the norm's subgradient 0 at n = 0
+ * (what torch autograd yields for x / (x.norm() + eps)). */
+int evdr_l2norm_fwd(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps,
+                    float* y, float* norm_or_null, void* hip_stream);
+int evdr_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask_or_null, const float* norm,
+                    int64_t rows, int64_t d, float eps, float* dx, void* hip_stream);
+
 /* ---- A8: top-k per query row, replaces the Nq*N .item() loop (mainv2_iter_distill_infonce.py:311-317)
  * scores (nq, n) fp32 with row stride `row_stride`; idx_map_or_null (nq, n) int32 maps a column to
  * the index to report (used when merging per-shard candidate lists), else column + idx_base.

@@ -234,6 +234,29 @@ def test_a6_full_gradient_identical_inputs(dev, ER):
     assert torch.equal(arg_d.cpu().to(torch.int32) & 0xFFFF, arg_o.to(torch.int32))
 
 
+def test_a4_l2norm_kernels(golden, dev):
+    """Fused normalise(+mask) forward/backward vs the reference's output (fixture) and vs torch autograd of the formula."""
+    from evdr_amd.utils.preprocess_data import l2_normalize, normalize_masked
+    z = golden("a4_l2norm")
+    x = T(z["x"]).to(dev)
+    np.testing.assert_allclose(l2_normalize(x).cpu().numpy(), z["y"], atol=1e-7, rtol=1e-6)
+    assert torch.all(l2_normalize(x)[0, 0] == 0)
+    gen = torch.Generator().manual_seed(3)
+    xr = torch.randn(7, 33, 128, generator=gen)
+    xr[2, 5] = 0.0
+    m = torch.rand(7, 33, generator=gen) > 0.3
+    gy = torch.randn(7, 33, 128, generator=gen)
+    xo = xr.clone().requires_grad_(True)
+    yo = O.l2_normalize(xo * m.unsqueeze(-1))
+    (yo * gy).sum().backward()
+    xd = xr.to(dev).requires_grad_(True)
+    yd = normalize_masked(xd, m.to(dev))
+    (yd * gy.to(dev)).sum().backward()
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), yo.detach().numpy(), atol=1e-7, rtol=1e-6)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xo.grad.numpy(), atol=1e-6, rtol=1e-5)
+    assert torch.all(xd.grad.cpu()[~m] == 0) and torch.isfinite(xd.grad).all()
+
+
 # ---- top-k --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,k", [(500, 100), (37, 100), (100, 100), (5000, 10), (100001, 100), (1, 1)])
 def test_topk_vs_oracle(dev, n, k):
