@@ -274,3 +274,60 @@ def main(argv=None):
 
 if __name__ == "__main__":
     main()
+
+
+# ----------------------------------------------------------------------------------------------------
+# Page-sharded training step (SURVEY §8(e) "Training partitioning"; no counterpart in the reference)
+# ----------------------------------------------------------------------------------------------------
+class _GatherColumns(torch.autograd.Function):
+    """(B, n_local) score block of this rank -> full (B, N) rows on every rank (all-gather over the page shards);
+    the backward keeps this rank's own columns of the upstream gradient: the parameters are sharded, not
+    replicated, so there is NO gradient all-reduce."""
+
+    @staticmethod
+    def forward(ctx, block, sizes, group):
+        import torch.distributed as dist
+        rank = dist.get_rank(group)
+        ctx.lo = int(sum(sizes[:rank]))
+        ctx.n_local = int(sizes[rank])
+        backend = dist.get_backend(group)
+        b = block.shape[0]
+        nmax = max(sizes)
+        msg = torch.zeros((b, nmax), dtype=torch.float32, device=block.device)      # equal-sized messages
+        msg[:, : block.shape[1]] = block
+        if backend == "gloo" and msg.is_cuda:                                       # CPU rehearsal of the exchange
+            host = msg.cpu()
+            buf = torch.empty((len(sizes) * b, nmax), dtype=torch.float32)
+            dist.all_gather_into_tensor(buf, host, group=group)
+            buf = buf.to(block.device)
+        else:                                                                       # nccl = RCCL over xGMI
+            buf = torch.empty((len(sizes) * b, nmax), dtype=torch.float32, device=block.device)
+            dist.all_gather_into_tensor(buf, msg, group=group)
+        buf = buf.view(len(sizes), b, nmax)
+        return torch.cat([buf[r, :, : sizes[r]] for r in range(len(sizes))], dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, ctx.lo: ctx.lo + ctx.n_local].contiguous(), None, None
+
+
+def sharded_train_one_step(Qb, qmb, teacher_shard, Pbar_shard, pmask_student_shard, opt, temp: float,
+                           shard_sizes, group=None) -> float:
+    """One InfoNCE-distillation update with the pages sharded over the ranks of `group`.
+
+    Every rank holds the SAME query batch, its own slice of the teacher pages (`teacher_shard`: a TeacherScorer over
+    the shard) and of the student parameter (`Pbar_shard`, with its own AdamW state).  Per step: local teacher and
+    student score blocks (B, n_local) -> ONE all-gather each (B*N*4 bytes in total: 64 KB at B=32, N=500) -> the
+    softmax / teacher arg-max are computed redundantly on the full rows -> each rank back-propagates only into its
+    own columns.  Identical arithmetic to the single-device step (the loss is the same number on every rank)."""
+    device = Pbar_shard.device
+    Qb = Qb.to(device, non_blocking=True)
+    qmb = qmb.to(device, non_blocking=True)
+    Psb = normalize_masked(Pbar_shard, pmask_student_shard)
+    sc_t = _GatherColumns.apply(teacher_shard.scores(Qb, qmb), tuple(shard_sizes), group)
+    sc_s = _GatherColumns.apply(score_multi_vector_masked(Qb, Psb, qmb, pmask_student_shard), tuple(shard_sizes), group)
+    loss = infonce_distillation_loss(sc_s, sc_t, temperature=temp)
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    return float(loss.item())

@@ -44,3 +44,33 @@ def test_two_rank_candidate_exchange():
         ret = m.dict()
         mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
         assert dict(ret) == {0: True, 1: True}
+
+
+def _worker_cols(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import evdr_amd  # noqa: F401
+        from evdr_amd.driver import _GatherColumns
+        g = torch.Generator().manual_seed(7)
+        full = torch.randn(5, 11, generator=g)                      # the "global" (B, N) score matrix
+        up = torch.randn(5, 11, generator=g)                        # upstream gradient on the full rows
+        sizes = (6, 5)                                              # ragged page shards
+        lo = sum(sizes[:rank])
+        block = full[:, lo:lo + sizes[rank]].clone().requires_grad_(True)
+        out = _GatherColumns.apply(block, sizes, None)
+        (out * up).sum().backward()
+        ret[rank] = bool(torch.equal(out.detach(), full) and torch.equal(block.grad, up[:, lo:lo + sizes[rank]]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_score_column_gather():
+    """Training partitioning (§8(e)): forward = all-gather of ragged column blocks, backward = own columns only."""
+    world = 2
+    port = 29900 + (os.getpid() % 1000)
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker_cols, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True, 1: True}
