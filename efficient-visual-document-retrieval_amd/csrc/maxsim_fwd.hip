@@ -298,7 +298,7 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
     if (nplanes == 1 && !want_argmax) {
         // bf16 scoring without argmax (retrieval / eval / teacher scores): the 16x16x32-shape kernel
         // (maxsim_fwd16.hip).  EVDR_FWD_VARIANT is an experiment switch read per launch:
-        // 0/unset = default geometry, 1|2 = alternative ring geometries, 100 = this file's 32x32x16 kernel.
+        // 0/unset = default (staged kernel for long pages), 1 = flat per-tile kernel, 100 = this file's 32x32x16 kernel.
         const char* e = getenv("EVDR_FWD_VARIANT");
         const int variant = e ? atoi(e) : 0;
         if (variant != 100) return evdr_launch_maxsim_fwd16(p, qw, variant, stream);

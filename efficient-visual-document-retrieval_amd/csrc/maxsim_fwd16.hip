@@ -39,9 +39,9 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// WAVES waves per workgroup, ST 32-patch tiles per ring stage, NSTAGE ring slots (NSTAGE-1 stages in flight
-// beyond the one being computed).  Two geometries are used: 8 waves / 96 KiB (one workgroup per CU) and
-// 4 waves / 64 KiB (two independent workgroups per CU, whose barriers do not couple the two waves of a SIMD).
+// Flat per-tile schedule: WAVES waves per workgroup, ST 32-patch tiles per ring stage, NSTAGE ring slots over the
+// block's flat tile stream (stages ignore page boundaries).  Used for short pages (< 8 tiles, e.g. the compressed
+// student pages); long pages take maxsim_fwd16s_kernel below.
 template <int QW, int WAVES, int ST, int NSTAGE>
 __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrFwdParams p) {
     constexpr int STAGE_BYTES = ST * TILE_BYTES;
@@ -239,6 +239,232 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
 }
 
 
+
+// ---- page-aligned stages, straight-line fast stage ---------------------------------------------------------------
+// Ring stages are aligned to pages: a page of T tiles is ceil(T/4) stages, the last one short (a 1030-patch page = 8
+// stages of 4 full tiles + 1 stage holding the 6-patch tail tile).  A stage whose 4 tiles are all valid and belong
+// to one page -- 32 of the 33 tiles of such a page -- runs as ONE basic block: 8 half-tile steps x 8 chains x 4 MFMAs
+// per wave with no branch, no scalar load and no wait other than the LDS counters in between, so the compiler overlaps
+// every v_max3 epilogue and every ds_read with MFMAs of the following chains (the per-tile schedule lost ~28 % of the
+// matrix pipe to the gaps between tiles).  Other stages (tail tile, masked pages) take the per-tile path.
+// Tile masks of prefix-style pages (flag bit2) are derived from the valid length; mask words are only read for pages
+// with holes.  The short stage re-fetches its last tile into the unused ring rows (+9 % L2->LDS traffic, no HBM).
+template <int QW, int ST, int NSTAGE>
+__global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
+    constexpr int WAVES = 8;
+    constexpr int STAGE_BYTES = ST * TILE_BYTES;
+    constexpr int G = ST * 8 / WAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15;
+    const int g = lane >> 4;
+
+    const int b = blockIdx.x;
+    const int xi = b >> 3;
+    const int qg = xi % p.n_qgroups;
+    const int chunk = (xi / p.n_qgroups) * 8 + (b & 7);
+    if (chunk >= p.n_chunks) return;
+    const int pg0 = chunk * p.pages_per_block;
+    const int npages = min(p.pages_per_block, p.np - pg0);
+    const int spp = (p.ntiles + ST - 1) / ST;             // stages per page
+    const int nstages = npages * spp;
+
+    const int q0 = (qg * WAVES + wave) * QW;
+    const bool active = q0 < p.nq;
+    bf16x8 bq[QW][2][4];
+    float qwt[QW][2];
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+        const int q = q0 + j;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int tok = 16 * t + c;
+            const bool ok = (q < p.nq) && (tok < p.lq);
+            const int64_t row = (int64_t)q * p.q_stride + (int64_t)(p.tok0 + tok) * EVDR_D + g * 8;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = *reinterpret_cast<const bf16x8*>(p.Q + row + s * 32);
+                bq[j][t][s] = v;
+            }
+            float w = 0.f;
+            if (ok) w = (p.qmask == nullptr || p.qmask[(int64_t)q * p.lq_total + p.tok0 + tok] != 0) ? 1.f : 0.f;
+            qwt[j][t] = w;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const uint32_t smem_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    // stage S = page (S / spp), tiles 4 (S % spp) .. +3 of that page (rows beyond the page are clamped: masked anyway)
+    auto issue_stage = [&](int S, int slot) {
+        const uint32_t sbase = smem_base + slot * STAGE_BYTES;
+        const int pgi = S / spp;
+        const int t0 = (S - pgi * spp) * ST;
+        const uint16_t* pbase = p.P + (int64_t)(pg0 + pgi) * p.p_stride;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int pc = wave * G + i;
+            const int tis = pc >> 3, piece = pc & 7;
+            // with a 2-slot ring every wait is vmcnt(0), so tiles beyond the page need not be fetched at all
+            if (NSTAGE == 2 && t0 + tis >= p.ntiles) continue;
+            const int rit = piece * 4 + (lane >> 4);
+            const int row = min((t0 + tis) * EVDR_TILE_PATCHES + rit, p.lp - 1);
+            const int csrc = (lane & 15) ^ (rit & 15);
+            lds_dma_16B(pbase + (int64_t)row * EVDR_D + csrc * 8,
+                        __builtin_amdgcn_readfirstlane(sbase + tis * TILE_BYTES + piece * 1024));
+        }
+    };
+
+    typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
+    cptr_t tilemask_c = (cptr_t)(uintptr_t)p.tilemask;
+    cptr_t pageflags_c = (cptr_t)(uintptr_t)p.pageflags;
+
+    float run[QW][2];
+    const int gx = g ^ c;
+    const char* a_lane = smem + c * (EVDR_D * 2);
+    auto load_half = [&](bf16x8 (&a)[4], const char* sbase, int tis, int u) {
+        const char* tb = sbase + tis * TILE_BYTES + u * (16 * EVDR_D * 2);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) a[s4] = *reinterpret_cast<const bf16x8*>(tb + (((4 * s4) ^ gx) << 4));
+    };
+    auto chains_full = [&](const bf16x8 (&a)[4]) {           // all 16 patches of the half valid
+#pragma unroll
+        for (int j = 0; j < QW; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4v acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s4], bq[j][t][s4], acc, 0, 0, 0);
+                float m = run[j][t];
+                m = __builtin_fmaxf(__builtin_fmaxf(m, acc[0]), acc[1]);
+                m = __builtin_fmaxf(__builtin_fmaxf(m, acc[2]), acc[3]);
+                run[j][t] = m;
+            }
+    };
+    auto chains_masked = [&](const bf16x8 (&a)[4], uint32_t bits) {
+        uint32_t mybits = bits >> (4 * g);
+        asm volatile("" : "+v"(mybits));
+#pragma unroll
+        for (int j = 0; j < QW; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4v acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s4], bq[j][t][s4], acc, 0, 0, 0);
+                float m = run[j][t];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m = __builtin_fmaxf(m, ((mybits >> i) & 1u) ? acc[i] : neg_inf());
+                run[j][t] = m;
+            }
+    };
+
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; ++i)
+        if (i < nstages) issue_stage(i, i);
+    int slot = 0, S = 0;
+    for (int pgi = 0; pgi < npages; ++pgi) {
+        const int page = pg0 + pgi;
+        const uint32_t pflags = pageflags_c[page];
+        const int vlen = (pflags & 4u) ? ((pflags & 2u) ? (int)(pflags >> 16) : p.lp) : -1;    // -1: page with holes
+#pragma unroll
+        for (int j = 0; j < QW; ++j) run[j][0] = run[j][1] = (pflags & 2u) ? -1e4f : neg_inf();
+
+        for (int k = 0; k < spp; ++k, ++S) {
+            if (NSTAGE >= 3 && S + 1 < nstages) wait_vmcnt<G>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (S + NSTAGE - 1 < nstages) issue_stage(S + NSTAGE - 1, slot == 0 ? NSTAGE - 1 : slot - 1);
+            const char* sbase = a_lane + slot * STAGE_BYTES;
+            if (active) {
+                const int t0 = k * ST;
+                if (vlen - t0 * EVDR_TILE_PATCHES >= ST * EVDR_TILE_PATCHES) {
+                    // ---- fast stage: 4 all-valid tiles of one page, one basic block
+                    bf16x8 alo[4], ahi[4];
+                    load_half(alo, sbase, 0, 0);
+                    load_half(ahi, sbase, 0, 1);
+#pragma unroll
+                    for (int tis = 0; tis < ST; ++tis) {
+                        chains_full(alo);
+                        if (tis + 1 < ST) load_half(alo, sbase, tis + 1, 0);
+                        chains_full(ahi);
+                        if (tis + 1 < ST) load_half(ahi, sbase, tis + 1, 1);
+                    }
+                } else {
+                    // ---- generic stage: per tile, per 16-patch half
+                    for (int tis = 0; tis < ST; ++tis) {
+                        const int tip = t0 + tis;
+                        if (tip >= p.ntiles) break;
+                        uint32_t tm;
+                        if (vlen >= 0) {
+                            const int rem = vlen - tip * EVDR_TILE_PATCHES;
+                            tm = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+                        } else {
+                            tm = tilemask_c[(int64_t)page * p.ntiles + tip];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const uint32_t bits = (tm >> (16 * u)) & 0xFFFFu;
+                            if (bits == 0u) continue;
+                            bf16x8 a[4];
+                            load_half(a, sbase, tis, u);
+                            if (bits == 0xFFFFu) chains_full(a); else chains_masked(a, bits);
+                        }
+                    }
+                }
+            }
+            slot = (slot == NSTAGE - 1) ? 0 : slot + 1;
+        }
+        // ---- page finished: fold lane groups, weight, reduce over tokens, store
+        if (active) {
+            const float has = (pflags & 1u) ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < QW; ++j) {
+                float cs = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float v = run[j][t];
+                    v = __builtin_fmaxf(v, __shfl_xor(v, 16));
+                    v = __builtin_fmaxf(v, __shfl_xor(v, 32));
+                    cs += v * has * qwt[j][t];
+                }
+                cs += __shfl_xor(cs, 8);
+                cs += __shfl_xor(cs, 4);
+                cs += __shfl_xor(cs, 2);
+                cs += __shfl_xor(cs, 1);
+                if (lane == 0 && q0 + j < p.nq) {
+                    float* o = p.out + (int64_t)(q0 + j) * p.out_stride + page;
+                    if (p.accumulate) atomicAdd(o, cs);
+                    else *o = cs;
+                }
+            }
+        }
+    }
+}
+
+template <int QW, int ST, int NSTAGE>
+hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
+    EvdrFwdParams p = pin;
+    constexpr int LDS = NSTAGE * ST * TILE_BYTES;
+    auto kern = maxsim_fwd16s_kernel<QW, ST, NSTAGE>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    p.ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
+    p.n_qgroups = (p.nq + 8 * QW - 1) / (8 * QW);
+    int64_t ppb = ((int64_t)p.np * p.n_qgroups) / 1536;
+    if (ppb < 1) ppb = 1;
+    if (ppb > 64) ppb = 64;
+    p.pages_per_block = (int)ppb;
+    p.n_chunks = (p.np + p.pages_per_block - 1) / p.pages_per_block;
+    const int64_t blocks = (int64_t)((p.n_chunks + 7) / 8) * 8 * p.n_qgroups;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(8 * 64), LDS, stream, p);
+    return hipGetLastError();
+}
+
 template <int QW, int WAVES, int ST, int NSTAGE>
 hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
@@ -264,18 +490,14 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
 
 }  // namespace
 
-// geom: 0 = 8 waves, 4-tile stages, 3 slots (96 KiB, 1 workgroup/CU); 1 = 4 waves, 4-tile stages, 2 slots (64 KiB,
-// 2 workgroups/CU); 2 = 4 waves, 2-tile stages, 4 slots (64 KiB, 2 workgroups/CU)
+// geom 0 (default): page-aligned 8-tile stages (maxsim_fwd16s_kernel) for pages of >= 8 tiles, the flat per-tile ring
+// (maxsim_fwd16_kernel) for shorter pages; geom 1 forces the flat kernel (A/B experiments).
 hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int geom, hipStream_t stream) {
-    if (geom == 1) {
-        if (qw == 4) return launch16<4, 4, 4, 2>(p, stream);
-        if (qw == 2) return launch16<2, 4, 4, 2>(p, stream);
-        return launch16<1, 4, 4, 2>(p, stream);
-    }
-    if (geom == 2) {
-        if (qw == 4) return launch16<4, 4, 2, 4>(p, stream);
-        if (qw == 2) return launch16<2, 4, 2, 4>(p, stream);
-        return launch16<1, 4, 2, 4>(p, stream);
+    const int ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
+    if (geom != 1 && ntiles >= 8) {
+        if (qw == 4) return launch16s<4, 8, 2>(p, stream);
+        if (qw == 2) return launch16s<2, 8, 2>(p, stream);
+        return launch16s<1, 8, 2>(p, stream);
     }
     if (qw == 4) return launch16<4, 8, 4, 3>(p, stream);
     if (qw == 2) return launch16<2, 8, 4, 3>(p, stream);

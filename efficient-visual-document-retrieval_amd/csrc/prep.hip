@@ -12,7 +12,7 @@ __global__ void __launch_bounds__(64) pack_pmask_kernel(const uint8_t* __restric
     const int page = blockIdx.x;
     const int lane = threadIdx.x;
     const uint8_t* row = pmask ? pmask + (int64_t)page * lp : nullptr;
-    uint32_t any_valid = 0, first_masked = 0xFFFFu;
+    uint32_t any_valid = 0, first_masked = 0xFFFFu, nvalid = 0;
     for (int t = lane; t < ntiles; t += 64) {
         uint32_t w = 0, inrange = 0;
         const int base = t * 32;
@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(64) pack_pmask_kernel(const uint8_t* __restric
         }
         tilemask[(int64_t)page * ntiles + t] = w;
         any_valid |= w;
+        nvalid += (uint32_t)__builtin_popcount(w);
         const uint32_t masked = inrange & ~w;
         if (masked) first_masked = min(first_masked, (uint32_t)(base + __builtin_ctz(masked)));
     }
@@ -33,10 +34,14 @@ __global__ void __launch_bounds__(64) pack_pmask_kernel(const uint8_t* __restric
     for (int off = 32; off > 0; off >>= 1) {
         any_valid |= __shfl_xor(any_valid, off);
         first_masked = min(first_masked, (uint32_t)__shfl_xor((int)first_masked, off));
+        nvalid += (uint32_t)__shfl_xor((int)nvalid, off);
     }
     if (lane == 0) {
         uint32_t f = (any_valid ? 1u : 0u);
         if (first_masked != 0xFFFFu) f |= 2u | (first_masked << 16);
+        // bit2: the valid patches are exactly the prefix [0, first_masked) (or the whole page): the tile masks are then a
+        // function of that length alone and the forward kernel derives them without loading the mask words
+        if (first_masked == 0xFFFFu || nvalid == first_masked) f |= 4u;
         pageflags[page] = f;
     }
 }

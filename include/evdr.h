@@ -49,6 +49,7 @@ const char* evdr_last_error(void);       /* host string, thread-local, valid unt
  * tilemask: np * ceil(lp/32) uint32 (bit m of word t = pmask[p][32 t + m]);
  * pageflags: np uint32 (bit0 = page has a valid patch  [doc_has_token, evaluator/retrieval.py:192],
  *                       bit1 = page has a masked patch [-1e4 fill takes part in the max, :198],
+ *                       bit2 = the valid patches form a prefix [0, first masked) or the whole page,
  *                       bits 16..31 = index of the first masked patch). */
 int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp,
                     uint32_t* tilemask, uint32_t* pageflags, void* hip_stream);

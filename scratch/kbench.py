@@ -7,10 +7,14 @@ sys.path.insert(0, "."); import bench as B
 pages = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 variants = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0,100").split(",")]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+zero = len(sys.argv) > 4 and sys.argv[4] == 'zero'
 dev = torch.device("cuda:0")
 P = B.gen_pages(0, pages, dev)
-corpus = PageCorpus.from_tensor(P, None)
+Q0 = None
 Q, _ = B.make_queries(1024, pages, P, 0, pages, dev, 1)
+if zero:
+    P.zero_(); Q.zero_(); print('ALL-ZERO DATA (clock experiment)')
+corpus = PageCorpus.from_tensor(P, None)
 out = torch.empty((1024, pages), dtype=torch.float32, device=dev)
 ref = None
 res = {v: [] for v in variants}
