@@ -64,7 +64,12 @@ def make_queries(nq: int, n_pages: int, shard, lo: int, hi: int, dev, world: int
         base = shard[t_local[:, None], rows[mine].to(dev)].float()                          # (m, LQ, D)
         Q[mine.to(dev)] = torch.nn.functional.normalize(base + 0.5 * eps[mine].to(dev), dim=-1)
     if world > 1:
-        dist.all_reduce(Q)
+        if dist.get_backend() == "gloo":
+            host = Q.cpu()
+            dist.all_reduce(host)
+            Q = host.to(dev)
+        else:
+            dist.all_reduce(Q)
     return Q.bfloat16(), targets
 
 
@@ -110,6 +115,8 @@ def main():
     ap.add_argument("--queries", type=int, default=1024, help="queries per step")
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse N>1 on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,11 +125,15 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)     # gloo rehearsal: several ranks may share a GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import evdr_amd  # noqa: F401
     from evdr_amd.corpus import PageCorpus, ShardedRetriever, shard_range
@@ -153,7 +164,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
