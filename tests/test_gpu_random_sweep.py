@@ -1,0 +1,75 @@
+"""Seeded random sweep over shapes, masks and dtypes: every forward kernel variant (staged 16x16 for long pages, flat
+16x16 for short pages, 32x32 with argmax, 3-plane fp32) against the oracle; argmax and dP against the oracle too."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maxsim_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    nq = [1, 3, 8, 9, 17, 32, 33, 40][ri(0, 7)]
+    lq = [1, 5, 16, 17, 32, 33, 50][ri(0, 6)]
+    npg = ri(1, 70)
+    lp = [1, 15, 16, 17, 31, 32, 33, 100, 206, 255, 256, 257, 300, 513, 1030][ri(0, 14)]
+    Q = torch.nn.functional.normalize(torch.randn(nq, lq, 128, generator=g), dim=-1).bfloat16()
+    P = torch.nn.functional.normalize(torch.randn(npg, lp, 128, generator=g), dim=-1).bfloat16()
+    style = ri(0, 3)
+    if style == 0:                                   # everything valid
+        pm = torch.ones(npg, lp, dtype=torch.bool)
+    elif style == 1:                                 # prefix-style (ragged lengths), some pages empty
+        lens = torch.randint(0, lp + 1, (npg,), generator=g)
+        pm = torch.arange(lp)[None, :] < lens[:, None]
+    elif style == 2:                                 # holes
+        pm = torch.rand(npg, lp, generator=g) > 0.35
+    else:                                            # masked prefix + valid tail (image-mask style)
+        cut = torch.randint(0, lp, (npg,), generator=g)
+        pm = torch.arange(lp)[None, :] >= cut[:, None]
+    qm = torch.rand(nq, lq, generator=g) > 0.25
+    return Q, P, qm, pm
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_forward_all_kernels(seed):
+    import evdr_amd  # noqa: F401
+    import evdr_amd.ops as ops
+    dev = torch.device("cuda:0")
+    Q, P, qm, pm = _case(seed)
+    want = O.maxsim_masked(Q.float(), P.float(), qm, pm)
+    args = (qm.to(dev), pm.to(dev))
+    for variant in ("0", "1", "100"):                # staged/auto, flat 16x16, 32x32
+        os.environ["EVDR_FWD_VARIANT"] = variant
+        try:
+            got, _ = ops.maxsim_forward(Q.to(dev), P.to(dev), *args)
+        finally:
+            os.environ.pop("EVDR_FWD_VARIANT", None)
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4, rtol=0, err_msg=f"variant {variant}")
+    got32, _ = ops.maxsim_forward(Q.float().to(dev), P.float().to(dev), *args)          # 3-plane fp32 path
+    np.testing.assert_allclose(got32.cpu().numpy(), want.numpy(), atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("seed", range(40, 60))
+def test_random_argmax_and_backward(seed):
+    import evdr_amd  # noqa: F401
+    import evdr_amd.ops as ops
+    dev = torch.device("cuda:0")
+    Q, P, qm, pm = _case(seed)
+    Qf, Pf = Q.float(), P.float()
+    s_o, arg_o = O.maxsim_masked_argmax(Qf, Pf, qm, pm)
+    g = torch.randn(s_o.shape, generator=torch.Generator().manual_seed(seed))
+    dP_o = O.maxsim_backward(g, Qf, Pf, qm, pm)
+    for Qx, Px in ((Q, P), (Qf, Pf)):                # bf16 kernel with argmax, fp32 (3-plane) kernel with argmax
+        s, arg = ops.maxsim_forward(Qx.to(dev), Px.to(dev), qm.to(dev), pm.to(dev), want_argmax=True)
+        np.testing.assert_allclose(s.cpu().numpy(), s_o.numpy(), atol=1e-4, rtol=0)
+        arg = arg.cpu().to(torch.int32) & 0xFFFF
+        # exact ties between DIFFERENT patches do not occur in random data; masked/empty pages resolve by rule
+        assert torch.equal(arg, arg_o.to(torch.int32))
+        dP = ops.maxsim_backward(g.to(dev), Qf.to(dev), qm.to(dev), pm.to(dev), (arg.to(torch.int16)).to(dev), P.shape[0], P.shape[1])
+        np.testing.assert_allclose(dP.cpu().numpy(), dP_o.numpy(), atol=2e-6, rtol=1e-5)   # fp32 sums of up to nq*lq terms per row, order differs
+        assert torch.all(dP.cpu()[~pm] == 0)
