@@ -71,5 +71,5 @@ def test_random_argmax_and_backward(seed):
         # exact ties between DIFFERENT patches do not occur in random data; masked/empty pages resolve by rule
         assert torch.equal(arg, arg_o.to(torch.int32))
         dP = ops.maxsim_backward(g.to(dev), Qf.to(dev), qm.to(dev), pm.to(dev), (arg.to(torch.int16)).to(dev), P.shape[0], P.shape[1])
-        np.testing.assert_allclose(dP.cpu().numpy(), dP_o.numpy(), atol=2e-6, rtol=1e-5)   # fp32 sums of up to nq*lq terms per row, order differs
+        np.testing.assert_allclose(dP.cpu().numpy(), dP_o.numpy(), atol=2e-5, rtol=1e-5)   # fp32 sums of up to nq*lq (=2000) terms per row in a different order: |err| ~ eps * sum|terms|
         assert torch.all(dP.cpu()[~pm] == 0)
