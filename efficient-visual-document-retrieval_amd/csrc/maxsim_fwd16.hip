@@ -11,6 +11,9 @@
 //   A[row c][k = 8g + j]   = patch (16u + c) of the tile, dims 32s + 8g + j      (u = 16-patch half, s = k-step)
 //   B[k = 8g + j][col c]   = token (16t + c) of the query, dims 32s + 8g + j      (t = token half)
 //   C/D[row 4g + reg][col c] -> lane holds, for token 16t + c, the patches 16u + 4g + reg, reg = 0..3
+#include <stdlib.h>
+#include <type_traits>
+
 #include "evdr_common.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
@@ -31,6 +34,22 @@ __device__ __forceinline__ void lds_dma_16B(const void* gsrc, uint32_t lds_base)
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gsrc), "s"(lds_base)
+        : "memory");
+}
+
+// Same LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: one VGPR per piece instead of
+// a 64-bit per-lane pointer (the staged kernel issues pieces in the middle of its MFMA block, where VGPRs are scarce).
+// s_nop 4 covers a base that was just produced by a VALU->SGPR move (cdna_hip_programming.md §5.7 item 2).
+__device__ __forceinline__ void lds_dma_16B_sbase(const void* sbase, uint32_t voff, uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_base)
         : "memory");
 }
 
@@ -249,7 +268,18 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
 // matrix pipe to the gaps between tiles).  Other stages (tail tile, masked pages) take the per-tile path.
 // Tile masks of prefix-style pages (flag bit2) are derived from the valid length; mask words are only read for pages
 // with holes.  The short stage re-fetches its last tile into the unused ring rows (+9 % L2->LDS traffic, no HBM).
-template <int QW, int ST, int NSTAGE>
+// DIAG instantiation: s_memtime stamps around the segments of a wave's life, summed per wave and written to p.dbg
+// ([block][wave][8] cycles: total, prologue, barrier wait, top-of-stage refill, fast block, generic stage, page
+// finish, stages).  Its fences forbid overlaps the real kernel has: read SHARES, never its run time.
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <int QW, int ST, int NSTAGE, bool DIAG = false, bool BAL = false>
 __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
     constexpr int WAVES = 8;
     constexpr int STAGE_BYTES = ST * TILE_BYTES;
@@ -270,6 +300,8 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
     const int npages = min(p.pages_per_block, p.np - pg0);
     const int spp = (p.ntiles + ST - 1) / ST;             // stages per page
     const int nstages = npages * spp;
+    unsigned long long d_t0 = 0, d_pro = 0, d_bar = 0, d_ref = 0, d_fast = 0, d_gen = 0, d_fin = 0, d_a = 0;
+    if constexpr (DIAG) d_t0 = stamp();
 
     const int q0 = (qg * WAVES + wave) * QW;
     const bool active = q0 < p.nq;
@@ -298,24 +330,36 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
 
     const uint32_t smem_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     // stage S = page (S / spp), tiles 4 (S % spp) .. +3 of that page (rows beyond the page are clamped: masked anyway)
-    auto issue_stage = [&](int S, int slot) {
-        const uint32_t sbase = smem_base + slot * STAGE_BYTES;
+    // Per-lane byte offset of this lane's 16 B inside a 1-KiB piece: LDS row (4 piece + lane/16) of the tile receives source
+    // chunk (lane%16) ^ (row & 15) of patch row (row0 + lane/16).  swz[q] = the swizzled chunk offset for piece & 3 == q.
+    // The DMA's lane offset is zero-extended, so rows past the page end (masked anyway) are clamped by clamping the
+    // scalar base row and giving each lane a non-negative row delta.
+    uint32_t swz[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) swz[q] = (uint32_t)(((lane & 15) ^ ((4 * q + (lane >> 4)) & 15)) << 4);
+    const uint32_t lgoff = (uint32_t)(lane >> 4) * 256u;
+    // piece i (of G) of this wave for stage S
+    auto issue_piece = [&](int S, int slot, int i, auto full_tag) {
+        constexpr bool KNOWN_FULL = decltype(full_tag)::value;       // caller guarantees the stage has all ST tiles
         const int pgi = S / spp;
         const int t0 = (S - pgi * spp) * ST;
-        const uint16_t* pbase = p.P + (int64_t)(pg0 + pgi) * p.p_stride;
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int pc = wave * G + i;
-            const int tis = pc >> 3, piece = pc & 7;
-            // with a 2-slot ring every wait is vmcnt(0), so tiles beyond the page need not be fetched at all
-            if (NSTAGE == 2 && t0 + tis >= p.ntiles) continue;
-            const int rit = piece * 4 + (lane >> 4);
-            const int row = min((t0 + tis) * EVDR_TILE_PATCHES + rit, p.lp - 1);
-            const int csrc = (lane & 15) ^ (rit & 15);
-            lds_dma_16B(pbase + (int64_t)row * EVDR_D + csrc * 8,
-                        __builtin_amdgcn_readfirstlane(sbase + tis * TILE_BYTES + piece * 1024));
-        }
+        const int pc = wave * G + i;
+        const int tis = pc >> 3, piece = pc & 7;
+        // with a 2-slot ring every wait is vmcnt(0), so tiles beyond the page need not be fetched at all
+        if (!KNOWN_FULL && NSTAGE == 2 && t0 + tis >= p.ntiles) return;
+        const int row0 = (t0 + tis) * EVDR_TILE_PATCHES + piece * 4;                 // first patch row of the piece (uniform)
+        const int rbase = min(row0, p.lp - 1);
+        const uint16_t* sb = p.P + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
+        uint32_t voff = swz[piece & 3] + lgoff;
+        if (!KNOWN_FULL && row0 + 3 >= p.lp)                                         // uniform: only a page's tail tile
+            voff = swz[piece & 3] + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
+        lds_dma_16B_sbase(sb, voff, __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + tis * TILE_BYTES + piece * 1024));
     };
+    auto issue_stage = [&](int S, int slot) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) issue_piece(S, slot, i, std::false_type{});
+    };
+    constexpr bool SPREAD = (NSTAGE == 2) && (G == ST);      // one piece per tile of the straight-line block
 
     typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
     cptr_t tilemask_c = (cptr_t)(uintptr_t)p.tilemask;
@@ -363,6 +407,7 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
 #pragma unroll
     for (int i = 0; i < NSTAGE - 1; ++i)
         if (i < nstages) issue_stage(i, i);
+    if constexpr (DIAG) d_pro = stamp() - d_t0;
     int slot = 0, S = 0;
     for (int pgi = 0; pgi < npages; ++pgi) {
         const int page = pg0 + pgi;
@@ -372,24 +417,67 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
         for (int j = 0; j < QW; ++j) run[j][0] = run[j][1] = (pflags & 2u) ? -1e4f : neg_inf();
 
         for (int k = 0; k < spp; ++k, ++S) {
+            if constexpr (DIAG) d_a = stamp();
             if (NSTAGE >= 3 && S + 1 < nstages) wait_vmcnt<G>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (S + NSTAGE - 1 < nstages) issue_stage(S + NSTAGE - 1, slot == 0 ? NSTAGE - 1 : slot - 1);
+            if constexpr (DIAG) { const unsigned long long t = stamp(); d_bar += t - d_a; d_a = t; }
+            const int nslot = slot == 0 ? NSTAGE - 1 : slot - 1;
+            const bool refill = S + NSTAGE - 1 < nstages;
+            const int t0 = k * ST;
+            const bool fast = active && (vlen - t0 * EVDR_TILE_PATCHES >= ST * EVDR_TILE_PATCHES);
+            // In-block refill: when this stage runs the straight-line block AND the next stage is a full one (all ST tiles
+            // exist and lie inside the page rows), its LDS-DMA pieces are issued one per tile INSIDE the block, where their
+            // scalar/address work hides under MFMAs; otherwise the refill is issued here, right after the barrier.
+            const bool next_full = refill && (k + 1 < spp ? (k + 2) * ST * EVDR_TILE_PATCHES <= p.lp
+                                                          : ST * EVDR_TILE_PATCHES <= p.lp);
+            const bool spread = SPREAD && fast && next_full;
+            if (refill && !spread) issue_stage(S + NSTAGE - 1, nslot);
+            if constexpr (DIAG) { const unsigned long long t = stamp(); d_ref += t - d_a; d_a = t; }
             const char* sbase = a_lane + slot * STAGE_BYTES;
             if (active) {
-                const int t0 = k * ST;
-                if (vlen - t0 * EVDR_TILE_PATCHES >= ST * EVDR_TILE_PATCHES) {
-                    // ---- fast stage: 4 all-valid tiles of one page, one basic block
-                    bf16x8 alo[4], ahi[4];
-                    load_half(alo, sbase, 0, 0);
-                    load_half(ahi, sbase, 0, 1);
+                if (fast) {
+                    // ---- fast stage: ST all-valid tiles of one page, one basic block (two instances: with / without refill)
+                    auto fast_block = [&](auto spread_tag, auto young_tag) {
+                        constexpr bool SP = decltype(spread_tag)::value;
+                        constexpr bool YOUNG = decltype(young_tag)::value;   // second-dispatched half of the workgroup
+                        bf16x8 alo[4], ahi[4];
+                        load_half(alo, sbase, 0, 0);
+                        load_half(ahi, sbase, 0, 1);
 #pragma unroll
-                    for (int tis = 0; tis < ST; ++tis) {
-                        chains_full(alo);
-                        if (tis + 1 < ST) load_half(alo, sbase, tis + 1, 0);
-                        chains_full(ahi);
-                        if (tis + 1 < ST) load_half(ahi, sbase, tis + 1, 1);
+                        for (int tis = 0; tis < ST; ++tis) {
+                            // self-balancing priority: 3,2,1,0 over the quarters of the block.  The two waves of a SIMD run this
+                            // same block; the one the arbiter favours reaches the lower-priority quarters first and yields, so
+                            // both arrive at the stage barrier together instead of one idling while the other finishes alone.
+                            if constexpr (BAL) {
+                                // priority falls with progress (tile index u): second-dispatched half 3,3,2,2,1,1,0,0;
+                                // first half, which wins equal-priority arbitration by age, half a step lower: 3,2,2,1,1,0,0,0
+                                static_assert(ST == 8, "priority schedule is written for 8-tile stages");
+                                if constexpr (YOUNG) {
+                                    if (tis == 0) __builtin_amdgcn_s_setprio(3);
+                                    else if (tis == 2) __builtin_amdgcn_s_setprio(2);
+                                    else if (tis == 4) __builtin_amdgcn_s_setprio(1);
+                                    else if (tis == 6) __builtin_amdgcn_s_setprio(0);
+                                } else {
+                                    if (tis == 0) __builtin_amdgcn_s_setprio(3);
+                                    else if (tis == 1) __builtin_amdgcn_s_setprio(2);
+                                    else if (tis == 3) __builtin_amdgcn_s_setprio(1);
+                                    else if (tis == 5) __builtin_amdgcn_s_setprio(0);
+                                }
+                            }
+                            chains_full(alo);
+                            if (tis + 1 < ST) load_half(alo, sbase, tis + 1, 0);
+                            if constexpr (SP) issue_piece(S + 1, nslot, tis, std::true_type{});
+                            chains_full(ahi);
+                            if (tis + 1 < ST) load_half(ahi, sbase, tis + 1, 1);
+                        }
+                    };
+                    // one straight-line instance per (refill placement, workgroup half): no run-time branch inside the block
+                    if (BAL && wave >= WAVES / 2) {
+                        if (spread) fast_block(std::true_type{}, std::true_type{}); else fast_block(std::false_type{}, std::true_type{});
+                    } else {
+                        if (spread) fast_block(std::true_type{}, std::false_type{}); else fast_block(std::false_type{}, std::false_type{});
                     }
+                    if constexpr (DIAG) { const unsigned long long t = stamp(); d_fast += t - d_a; d_a = t; }
                 } else {
                     // ---- generic stage: per tile, per 16-patch half
                     for (int tis = 0; tis < ST; ++tis) {
@@ -413,8 +501,10 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
                     }
                 }
             }
+            if constexpr (DIAG) { if (!fast) { const unsigned long long t = stamp(); d_gen += t - d_a; d_a = t; } }
             slot = (slot == NSTAGE - 1) ? 0 : slot + 1;
         }
+        if constexpr (DIAG) d_a = stamp();
         // ---- page finished: fold lane groups, weight, reduce over tokens, store
         if (active) {
             const float has = (pflags & 1u) ? 1.f : 0.f;
@@ -439,14 +529,22 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
                 }
             }
         }
+        if constexpr (DIAG) d_fin += stamp() - d_a;
+    }
+    if constexpr (DIAG) {
+        if (p.dbg != nullptr && lane == 0 && blockIdx.x < 4096) {
+            unsigned long long* o = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+            o[0] = stamp() - d_t0; o[1] = d_pro; o[2] = d_bar; o[3] = d_ref; o[4] = d_fast; o[5] = d_gen; o[6] = d_fin;
+            o[7] = (unsigned long long)nstages;
+        }
     }
 }
 
-template <int QW, int ST, int NSTAGE>
+template <int QW, int ST, int NSTAGE, bool DIAG = false, bool BAL = false>
 hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
     constexpr int LDS = NSTAGE * ST * TILE_BYTES;
-    auto kern = maxsim_fwd16s_kernel<QW, ST, NSTAGE>;
+    auto kern = maxsim_fwd16s_kernel<QW, ST, NSTAGE, DIAG, BAL>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -490,14 +588,22 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
 
 }  // namespace
 
-// geom 0 (default): page-aligned 8-tile stages (maxsim_fwd16s_kernel) for pages of >= 8 tiles, the flat per-tile ring
-// (maxsim_fwd16_kernel) for shorter pages; geom 1 forces the flat kernel (A/B experiments).
+// geom 0 (default): page-aligned 8-tile stages with the self-balancing priority schedule (maxsim_fwd16s_kernel) for pages
+// of >= 8 tiles, the flat per-tile ring (maxsim_fwd16_kernel) for shorter pages; geom 1 forces the flat kernel, geom 2 the
+// staged kernel without the priority schedule (A/B experiments); 50/51 are the stamped diagnostic builds.
 hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int geom, hipStream_t stream) {
     const int ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
+    if ((geom == 50 || geom == 51) && ntiles >= 8 && qw == 4) {   // diagnostic builds with in-kernel stamps (scratch/diag_stamps.py)
+        EvdrFwdParams pd = p;
+        const char* e = getenv("EVDR_DBG_PTR");
+        pd.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr;
+        return geom == 50 ? launch16s<4, 8, 2, true, false>(pd, stream) : launch16s<4, 8, 2, true, true>(pd, stream);
+    }
+    if (geom == 2 && ntiles >= 8 && qw == 4) return launch16s<4, 8, 2, false, false>(p, stream);   // A/B: no priority schedule
     if (geom != 1 && ntiles >= 8) {
-        if (qw == 4) return launch16s<4, 8, 2>(p, stream);
-        if (qw == 2) return launch16s<2, 8, 2>(p, stream);
-        return launch16s<1, 8, 2>(p, stream);
+        if (qw == 4) return launch16s<4, 8, 2, false, true>(p, stream);
+        if (qw == 2) return launch16s<2, 8, 2, false, true>(p, stream);
+        return launch16s<1, 8, 2, false, true>(p, stream);
     }
     if (qw == 4) return launch16<4, 8, 4, 3>(p, stream);
     if (qw == 2) return launch16<2, 8, 4, 3>(p, stream);

@@ -1,0 +1,29 @@
+"""In-kernel stamp shares of the staged MaxSim kernel (diagnostic instantiation; shares only, not run time)."""
+import os, sys, torch
+sys.path.insert(0, "."); import evdr_amd, bench as B
+from evdr_amd.corpus import PageCorpus
+dev = torch.device("cuda:0"); pages = 20000
+P = B.gen_pages(0, pages, dev); corpus = PageCorpus.from_tensor(P, None)
+Q, _ = B.make_queries(1024, pages, P, 0, pages, dev, 1)
+out = torch.empty((1024, pages), dtype=torch.float32, device=dev)
+dbg = torch.zeros((4096, 8, 8), dtype=torch.int64, device=dev)
+os.environ["EVDR_DBG_PTR"] = hex(dbg.data_ptr()); os.environ["EVDR_FWD_VARIANT"] = sys.argv[1] if len(sys.argv) > 1 else "50"
+for _ in range(3): corpus.score(Q, None, out=out)
+torch.cuda.synchronize()
+d = dbg.cpu().double(); d = d[d[:, :, 0] > 0]            # waves that reported
+tot = d[:, 0]
+names = ["total", "prologue", "barrier wait", "refill at stage top", "fast block", "generic stage", "page finish"]
+print(f"waves reporting: {len(d)}, stages per block: {d[:,7].mean():.1f}, mean total cycles {tot.mean():.0f}")
+for i, n in enumerate(names[1:], 1):
+    print(f"{n:22s} {100*(d[:, i]/tot).mean():6.2f} %   ({d[:, i].mean()/d[:,7].mean():8.0f} cycles per stage)")
+print(f"{'unaccounted':22s} {100*(1 - (d[:,1:7].sum(1)/tot)).mean():6.2f} %")
+# fast block: 512 MFMA x 16 cycles = 8192 issue cycles per wave per full stage
+nfast = d[:, 7] * 4 / 5
+print(f"fast block cycles per full stage: {(d[:,4]/nfast).mean():.0f}  (MFMA issue floor for ONE wave 8192; two waves share a SIMD -> 16384)")
+
+raw = dbg.cpu().double()
+ok = raw[:, :, 0].min(dim=1).values > 0
+r = raw[ok]
+print("per wave slot: barrier wait / fast block cycles per stage")
+for w in range(8):
+    print(f"  wave {w}: barrier {r[:, w, 2].mean()/r[:, w, 7].mean():7.0f}   fast {r[:, w, 4].mean()/(r[:, w, 7].mean()*0.8):7.0f}")
