@@ -338,3 +338,50 @@ def test_sharded_merge_equals_single_shard(dev):
     sc, ix = unpack_candidates(torch.stack(msgs))
     ms, mi = merge_candidates(sc, ix, k)
     assert torch.equal(mi, fi) and torch.equal(ms, fs)
+
+
+# ---- stream and graph behaviour promised by include/evdr.h ---------------------------------------------------------
+def test_runs_on_callers_stream_without_sync(dev, ER):
+    """Work is enqueued on torch's CURRENT stream (SURVEY §8(b) threading): results computed on a side stream are
+    correct once that stream is waited on, and inputs produced on that stream are consumed in order."""
+    gen = torch.Generator().manual_seed(21)
+    Q = torch.nn.functional.normalize(torch.randn(24, 32, 128, generator=gen), dim=-1).bfloat16().to(dev)
+    P = torch.nn.functional.normalize(torch.randn(96, 300, 128, generator=gen), dim=-1).bfloat16().to(dev)
+    qm = torch.ones(24, 32, dtype=torch.bool, device=dev)
+    pm = torch.ones(96, 300, dtype=torch.bool, device=dev)
+    want = ER.score_multi_vector_masked(Q, P, qm, pm).clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        P2 = P * 2                                        # producer on the side stream
+        got = ER.score_multi_vector_masked(Q, P2, qm, pm) # must run after it, on the same stream
+        back = got / 2
+    torch.cuda.current_stream(dev).wait_stream(side)
+    np.testing.assert_allclose(back.cpu().numpy(), want.cpu().numpy(), atol=2e-5)
+
+
+def test_hip_graph_capture_and_replay(dev):
+    """The prepared-corpus scorer and the top-k launch nothing but kernels (no allocation, no sync inside the C ABI):
+    a captured graph replays them and tracks updated inputs."""
+    import evdr_amd.ops as ops
+    from evdr_amd.corpus import PageCorpus
+    gen = torch.Generator().manual_seed(22)
+    P = torch.nn.functional.normalize(torch.randn(200, 260, 128, generator=gen), dim=-1).bfloat16().to(dev)
+    corpus = PageCorpus.from_tensor(P)
+    Qs = torch.nn.functional.normalize(torch.randn(40, 32, 128, generator=gen), dim=-1).bfloat16().to(dev)   # static input
+    out = torch.empty((40, 200), dtype=torch.float32, device=dev)
+    corpus.score(Qs, None, out=out)                        # warm-up outside capture (kernel attributes, lib load)
+    ops.topk(out, 10)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        corpus.score(Qs, None, out=out)
+        ts, ti = ops.topk(out, 10)
+    Qn = torch.nn.functional.normalize(torch.randn(40, 32, 128, generator=gen), dim=-1).bfloat16().to(dev)
+    Qs.copy_(Qn)
+    g.replay()
+    torch.cuda.synchronize()
+    want = O.maxsim_masked(Qn.float().cpu(), P.float().cpu(), torch.ones(40, 32, dtype=torch.bool), torch.ones(200, 260, dtype=torch.bool))
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), atol=SCORE_ATOL)
+    ws, wi = O.topk_rows(out.cpu(), 10)
+    assert torch.equal(ti.cpu(), wi)
