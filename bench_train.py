@@ -54,13 +54,16 @@ def main():
     def run(kind):
         param = torch.nn.Parameter(Pbar0.clone())
         opt = torch.optim.AdamW([param], lr=1e-3, weight_decay=1e-2)
-        teacher = driver.TeacherScorer(Pt, pmt, cache_size=Qall.shape[0] if kind == "cached" else 0) if kind != "call_pattern" and kind != "eager" else None
+        teacher = driver.TeacherScorer(Pt, pmt, cache_size=Qall.shape[0] if kind in ("cached", "fused_cached") else 0) if kind not in ("call_pattern", "eager") else None
+        student = driver.FusedStudent(Pbar0.clone(), pms, lr=1e-3, weight_decay=1e-2) if kind.startswith("fused") else None
 
         def step(i):
             idx = torch.arange(B) + (i % 64) * B
             Qb, qmb = Qall[idx], qmall[idx]
             if kind in ("resident", "cached"):
                 return driver.train_one_step(Qb, qmb, teacher, pmt, param, pms, opt, temp=0.1, qidx=idx if kind == "cached" else None)
+            if kind in ("fused", "fused_cached"):
+                return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached" else None)
             score = eager_maxsim if kind == "eager" else score_multi_vector_masked
             Psb = l2_normalize(param * pms.unsqueeze(-1))
             with torch.no_grad():
@@ -75,7 +78,7 @@ def main():
             opt.step()
             return float(loss.item())
 
-        if kind == "cached":
+        if kind in ("cached", "fused_cached"):
             for i in range(64):
                 step(i)                                   # fill the teacher-score cache (one epoch)
         for i in range(a.warmup):
@@ -88,7 +91,7 @@ def main():
         return 1e3 * (time.perf_counter() - t0) / a.steps, last
 
     res = {}
-    for kind in ["call_pattern", "resident", "cached"] + (["eager"] if a.eager else []):
+    for kind in ["call_pattern", "resident", "cached", "fused", "fused_cached"] + (["eager"] if a.eager else []):
         ms, loss = run(kind)
         res[kind] = {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "last_loss": loss}
     print(json.dumps({"metric": "InfoNCE-distillation step time", "unit": "ms/step", "higher_is_better": False,

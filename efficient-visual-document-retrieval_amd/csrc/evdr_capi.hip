@@ -1,5 +1,6 @@
 // C-ABI entry points (include/evdr.h).  Argument checking + workspace carving + kernel dispatch.
 // Nothing here allocates, frees or synchronises (graph-capture safe); errors come back as status codes.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -173,6 +174,24 @@ int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const 
     if (nq > 0 && lq > 0 && (!g || !Q || !argmax)) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd: null g/Q/argmax");
     hipError_t e = evdr_launch_maxsim_bwd(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, (hipStream_t)hip_stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd launch");
+}
+
+int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
+                          float* x, float* exp_avg, float* exp_avg_sq, int64_t nq, int64_t lq, int64_t np, int64_t lp,
+                          int64_t d, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                          float l2_eps, void* hip_stream) {
+    if (int rc = check_common(nq, lq, np, lp)) return rc;
+    if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported", (long long)d);
+    if (step < 1) return fail(EVDR_ERR_ARG, "step must be >= 1 (1 for the first update)");
+    if (np == 0 || lp == 0) return EVDR_OK;
+    if (!x || !exp_avg || !exp_avg_sq) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_adamw: null parameter/state");
+    if (nq > 0 && lq > 0 && (!g || !Q || !argmax)) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_adamw: null g/Q/argmax");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipError_t e = evdr_launch_maxsim_bwd_adamw(g, Q, qmask, pmask, argmax, x, exp_avg, exp_avg_sq, nq, lq, np, lp, lr, beta1,
+                                                beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), l2_eps,
+                                                (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd_adamw launch");
 }
 
 int evdr_l2norm_fwd(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps, float* y,

@@ -19,13 +19,25 @@ constexpr int BW_ROWS_MAX = 256;      // patch rows of dP owned by one workgroup
 // bucket with four 512-B query-row loads in flight, accumulates in registers and adds into the slab with plain LDS
 // accesses.  Every dP element is written to HBM exactly once; masked rows come out as exact zeros.
 // The order of the additions inside one row follows the scatter order (not fixed run to run, like index_add_ on a GPU).
-template <int BW_ROWS, int CHUNK>
+// FUSED: instead of writing dP (the gradient w.r.t. the NORMALISED pages), the epilogue continues on the slab in LDS:
+// l2-normalise backward through y = m x / (||m x|| + eps_n)  ->  AdamW on the raw parameter x (torch semantics: decoupled
+// weight decay, bias-corrected moments), in place on x / exp_avg / exp_avg_sq.  One kernel replaces maxsim_bwd + the
+// normalise/mask backward + torch's five multi-tensor AdamW kernels, and dP never goes to HBM.
+struct AdamArgs {
+    float* x;            // (np, lp, 128) raw parameter, updated in place
+    float* exp_avg;      // first moment
+    float* exp_avg_sq;   // second moment
+    float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, eps_norm;
+};
+
+template <int BW_ROWS, int CHUNK, bool FUSED>
 __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __restrict__ g,
                                                                const float* __restrict__ Q,
                                                                const uint8_t* __restrict__ qmask,
                                                                const uint8_t* __restrict__ pmask,
                                                                const uint16_t* __restrict__ argmax,
-                                                               float* __restrict__ dP, int nq, int lq, int np, int lp) {
+                                                               float* __restrict__ dP, int nq, int lq, int np, int lp,
+                                                               AdamArgs ad) {
     constexpr int PER_THREAD = CHUNK / BW_THREADS;
     constexpr int NGROUPS = BW_THREADS / 16;
     extern __shared__ __attribute__((aligned(16))) float acc[];          // [BW_ROWS][128]
@@ -127,8 +139,52 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
             __syncthreads();
         }
     }
-    f32x4* out = reinterpret_cast<f32x4*>(dP + ((int64_t)page * lp + r0) * EVDR_D);
-    for (int i = tid; i < rows * (EVDR_D / 4); i += BW_THREADS) out[i] = reinterpret_cast<const f32x4*>(acc)[i];
+    if constexpr (!FUSED) {
+        f32x4* out = reinterpret_cast<f32x4*>(dP + ((int64_t)page * lp + r0) * EVDR_D);
+        for (int i = tid; i < rows * (EVDR_D / 4); i += BW_THREADS) out[i] = reinterpret_cast<const f32x4*>(acc)[i];
+    } else {
+        // one 16-lane group per parameter row: 8 floats per lane
+        for (int r = gid; r < rows; r += NGROUPS) {
+            const int64_t off = ((int64_t)page * lp + r0 + r) * EVDR_D + sub * 8;
+            const float m = (pmask == nullptr || pmask[(int64_t)page * lp + r0 + r] != 0) ? 1.f : 0.f;
+            f32x4 x0 = *reinterpret_cast<const f32x4*>(ad.x + off), x1 = *reinterpret_cast<const f32x4*>(ad.x + off + 4);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(acc + r * EVDR_D + sub * 8);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(acc + r * EVDR_D + sub * 8 + 4);
+            // ---- backward of y = (m x) / (||m x|| + eps_n)
+            const f32x4 v0 = x0 * m, v1 = x1 * m;
+            float ss = v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3] + v1[0] * v1[0] + v1[1] * v1[1] +
+                       v1[2] * v1[2] + v1[3] * v1[3];
+            float dot = v0[0] * g0[0] + v0[1] * g0[1] + v0[2] * g0[2] + v0[3] * g0[3] + v1[0] * g1[0] + v1[1] * g1[1] +
+                        v1[2] * g1[2] + v1[3] * g1[3];
+            for (int o = 8; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
+            const float n = sqrtf(ss);
+            const float inv = 1.f / (n + ad.eps_norm);
+            const float c = (n > 0.f) ? dot * inv * inv / n : 0.f;
+            const f32x4 d0 = (g0 * inv - v0 * c) * m, d1 = (g1 * inv - v1 * c) * m;
+            // ---- AdamW (torch.optim.AdamW, amsgrad=False, maximize=False)
+            f32x4 ea0 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off), ea1 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off + 4);
+            f32x4 es0 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off), es1 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off + 4);
+            const float decay = 1.f - ad.lr * ad.weight_decay;
+            const float step_size = ad.lr / ad.bc1;
+            x0 *= decay;
+            x1 *= decay;
+            ea0 = ea0 * ad.beta1 + d0 * (1.f - ad.beta1);
+            ea1 = ea1 * ad.beta1 + d1 * (1.f - ad.beta1);
+            es0 = es0 * ad.beta2 + d0 * d0 * (1.f - ad.beta2);
+            es1 = es1 * ad.beta2 + d1 * d1 * (1.f - ad.beta2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                x0[k] -= step_size * (ea0[k] / (sqrtf(es0[k]) / ad.bc2_sqrt + ad.eps));
+                x1[k] -= step_size * (ea1[k] / (sqrtf(es1[k]) / ad.bc2_sqrt + ad.eps));
+            }
+            *reinterpret_cast<f32x4*>(ad.x + off) = x0;
+            *reinterpret_cast<f32x4*>(ad.x + off + 4) = x1;
+            *reinterpret_cast<f32x4*>(ad.exp_avg + off) = ea0;
+            *reinterpret_cast<f32x4*>(ad.exp_avg + off + 4) = ea1;
+            *reinterpret_cast<f32x4*>(ad.exp_avg_sq + off) = es0;
+            *reinterpret_cast<f32x4*>(ad.exp_avg_sq + off + 4) = es1;
+        }
+    }
     (void)lane;
 }
 
@@ -251,11 +307,11 @@ __global__ void __launch_bounds__(256) mean_kernel(const float* __restrict__ x, 
 
 }  // namespace
 
-template <int BW_ROWS, int CHUNK>
+template <int BW_ROWS, int CHUNK, bool FUSED>
 static hipError_t launch_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
-                             float* dP, int64_t nq, int64_t lq, int64_t np, int64_t lp, hipStream_t stream) {
+                             float* dP, int64_t nq, int64_t lq, int64_t np, int64_t lp, const AdamArgs& ad, hipStream_t stream) {
     constexpr int LDS = BW_ROWS * EVDR_D * 4 + CHUNK * 8 + BW_ROWS * 12;
-    auto kern = maxsim_bwd_kernel<BW_ROWS, CHUNK>;
+    auto kern = maxsim_bwd_kernel<BW_ROWS, CHUNK, FUSED>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -264,19 +320,33 @@ static hipError_t launch_bwd(const float* g, const float* Q, const uint8_t* qmas
     }
     dim3 grid((unsigned)np, (unsigned)((lp + BW_ROWS - 1) / BW_ROWS));
     hipLaunchKernelGGL(kern, grid, dim3(BW_THREADS), LDS, stream, g, Q, qmask, pmask, argmax, dP, (int)nq, (int)lq, (int)np,
-                       (int)lp);
+                       (int)lp, ad);
     return hipGetLastError();
+}
+
+template <bool FUSED>
+static hipError_t dispatch_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
+                               float* dP, int64_t nq, int64_t lq, int64_t np, int64_t lp, const AdamArgs& ad, hipStream_t stream) {
+    if (np == 0 || lp == 0) return hipSuccess;
+    // a whole compressed page (the mf >= 5 students: <= 256 patches) is one slab, so every pair is bucketed once;
+    // longer pages are cut into 128-row slabs (two workgroups per CU)
+    if (lp > 128 && lp <= BW_ROWS_MAX)
+        return launch_bwd<BW_ROWS_MAX, 2048, FUSED>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, ad, stream);
+    return launch_bwd<128, 1024, FUSED>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, ad, stream);
 }
 
 hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                   const uint16_t* argmax, float* dP, int64_t nq, int64_t lq, int64_t np, int64_t lp,
                                   hipStream_t stream) {
-    if (np == 0 || lp == 0) return hipSuccess;
-    // a whole compressed page (the mf >= 5 students: <= 256 patches) is one slab, so every pair is bucketed once;
-    // longer pages are cut into 128-row slabs (two workgroups per CU)
-    if (lp <= 128) return launch_bwd<128, 1024>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, stream);
-    if (lp <= BW_ROWS_MAX) return launch_bwd<BW_ROWS_MAX, 2048>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, stream);
-    return launch_bwd<128, 1024>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, stream);
+    return dispatch_bwd<false>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, AdamArgs{}, stream);
+}
+
+hipError_t evdr_launch_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
+                                        const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq, int64_t nq,
+                                        int64_t lq, int64_t np, int64_t lp, float lr, float beta1, float beta2, float eps,
+                                        float weight_decay, float bc1, float bc2_sqrt, float eps_norm, hipStream_t stream) {
+    AdamArgs ad{x, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, eps_norm};
+    return dispatch_bwd<true>(g, Q, qmask, pmask, argmax, nullptr, nq, lq, np, lp, ad, stream);
 }
 
 hipError_t evdr_launch_l2norm_fwd(const float* x, const uint8_t* rowmask, int64_t rows, float eps, float* y, float* norm,

@@ -168,6 +168,9 @@ def build_argparser():
     p.add_argument("--print_every", type=int, default=20)
     p.add_argument("--device", type=str, default="auto")
     p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--fused_step", action="store_true",
+                   help="student update through evdr_maxsim_bwd_adamw (backward + normalise backward + AdamW in one kernel; "
+                        "result-identical to autograd + torch.optim.AdamW)")
     p.add_argument("--cache_teacher_scores", action="store_true",
                    help="keep the (n_train_queries, N) teacher score matrix on the device (result-identical)")
     return p
@@ -208,8 +211,15 @@ def run(args) -> None:
             Pbar_raw, pmask_s, _ = preprocess_docs(Pbar_obj, attn_in, img_in, device)
             if Pbar_raw.shape[0] != n_pages:
                 raise ValueError(f"init doc count mismatch: got {Pbar_raw.shape[0]} vs teacher {n_pages}")
-            Pbar_param = nn.Parameter(Pbar_raw * pmask_s.unsqueeze(-1))
-            opt = set_optimizer(args.opt, Pbar_param, args.lr, args.weight_decay)
+            if args.fused_step:
+                if args.opt != "adamw":
+                    raise ValueError("--fused_step implements AdamW only")
+                student = FusedStudent(Pbar_raw, pmask_s, lr=args.lr, weight_decay=args.weight_decay)
+                Pbar_param, opt = student.x, None                 # evaluated / checkpointed through the same tensor
+            else:
+                student = None
+                Pbar_param = nn.Parameter(Pbar_raw * pmask_s.unsqueeze(-1))
+                opt = set_optimizer(args.opt, Pbar_param, args.lr, args.weight_decay)
             out_dir = Path(args.out_root) / args.name / f"mf{mf}" / dataset
             out_dir.mkdir(parents=True, exist_ok=True)
             logger, tb = get_logger(out_dir)
@@ -237,8 +247,12 @@ def run(args) -> None:
                     perm, cursor = torch.randperm(n_train, generator=gen), 0
                 idx = perm[cursor:cursor + args.q_batch]
                 cursor += args.q_batch
-                loss_val = train_one_step(Q_train[idx], qmask_train[idx], teacher, pmask_t, Pbar_param, pmask_s, opt,
-                                          temp=args.temp, qidx=idx if args.cache_teacher_scores else None)
+                qidx = idx if args.cache_teacher_scores else None
+                if student is not None:
+                    loss_val = fused_train_one_step(Q_train[idx], qmask_train[idx], teacher, student, args.temp, qidx=qidx)
+                else:
+                    loss_val = train_one_step(Q_train[idx], qmask_train[idx], teacher, pmask_t, Pbar_param, pmask_s, opt,
+                                              temp=args.temp, qidx=qidx)
                 loss_sum += loss_val
                 loss_cnt += 1
                 if tb is not None:
@@ -274,6 +288,46 @@ def main(argv=None):
 
 if __name__ == "__main__":
     main()
+
+
+# ----------------------------------------------------------------------------------------------------
+# Fused student update: no autograd graph, four launches per step on the student side
+# ----------------------------------------------------------------------------------------------------
+class FusedStudent:
+    """Student page embeddings with their AdamW state, updated by ONE kernel per step: MaxSim backward gather ->
+    l2-normalise(+mask) backward -> AdamW (evdr_maxsim_bwd_adamw).  Same arithmetic as
+    `Psb = l2_normalize(Pbar * pmask); ...; loss.backward(); torch.optim.AdamW.step()` of the reference's step
+    (mainv2_iter_distill_infonce.py:279-291, utils/utils.py:78-80: torch defaults betas (0.9, 0.999), eps 1e-8)."""
+
+    def __init__(self, Pbar_init: torch.Tensor, pmask_student: torch.Tensor, lr: float, weight_decay: float,
+                 betas=(0.9, 0.999), eps: float = 1e-8, l2_eps: float = 1e-12):
+        self.pmask = pmask_student.bool().contiguous()
+        self.x = (Pbar_init.detach().float() * self.pmask.unsqueeze(-1)).contiguous()
+        self.exp_avg = torch.zeros_like(self.x)
+        self.exp_avg_sq = torch.zeros_like(self.x)
+        self.lr, self.weight_decay, self.betas, self.eps, self.l2_eps = lr, weight_decay, betas, eps, l2_eps
+        self.steps = 0
+
+    def normalized(self) -> torch.Tensor:
+        return ops.l2norm_forward(self.x, self.pmask, self.l2_eps)[0]
+
+    def update(self, Qb, qmb, sc_t, temp: float) -> torch.Tensor:
+        """One step given the teacher scores; returns the loss as a device scalar (no host sync)."""
+        Psb = self.normalized()
+        sc_s, arg = ops.maxsim_forward(Qb, Psb, qmb, self.pmask, want_argmax=True)
+        loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True)
+        self.steps += 1
+        ops.maxsim_backward_adamw(dscore, Qb, qmb, self.pmask, arg, self.x, self.exp_avg, self.exp_avg_sq, self.lr,
+                                  self.betas, self.eps, self.weight_decay, self.steps, self.l2_eps)
+        return loss
+
+
+def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStudent, temp: float,
+                         qidx: Optional[torch.Tensor] = None) -> float:
+    device = student.x.device
+    Qb = Qb.to(device, non_blocking=True)
+    qmb = qmb.to(device, non_blocking=True)
+    return float(student.update(Qb, qmb, teacher.scores(Qb, qmb, qidx), temp).item())
 
 
 # ----------------------------------------------------------------------------------------------------

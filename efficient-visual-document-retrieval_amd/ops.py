@@ -199,3 +199,25 @@ def l2norm_backward(gy: torch.Tensor, x: torch.Tensor, rowmask: Optional[torch.T
         L.check(lib.evdr_l2norm_bwd(L.ptr(gc), L.ptr(xc), L.ptr(m), L.ptr(norm), rows, D, float(eps), L.ptr(dx),
                                     L.current_stream_handle(dev)))
     return dx
+
+
+def maxsim_backward_adamw(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],
+                          argmax: torch.Tensor, x: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+                          lr: float, betas: Tuple[float, float], eps: float, weight_decay: float, step: int,
+                          l2_eps: float = 1e-12) -> None:
+    """A6 + normalise/mask backward + AdamW in one launch, in place on x / exp_avg / exp_avg_sq (fp32, contiguous)."""
+    dev = _require_cuda(g, Q, argmax, x, exp_avg, exp_avg_sq)
+    for t in (x, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != x.shape:
+            raise RuntimeError("x / exp_avg / exp_avg_sq must be contiguous fp32 tensors of one shape")
+    npg, lp, d = x.shape
+    nq, lq, _ = Q.shape
+    lib = L.load()
+    gc, Qc = g.float().contiguous(), Q.float().contiguous()
+    qm = _mask_u8(qmask, (nq, lq), dev)
+    pm = _mask_u8(pmask, (npg, lp), dev)
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_maxsim_bwd_adamw(L.ptr(gc), L.ptr(Qc), L.ptr(qm), L.ptr(pm), L.ptr(argmax), L.ptr(x), L.ptr(exp_avg),
+                                          L.ptr(exp_avg_sq), nq, lq, npg, lp, d, float(lr), float(betas[0]), float(betas[1]),
+                                          float(eps), float(weight_decay), int(step), float(l2_eps),
+                                          L.current_stream_handle(dev)))

