@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--only", type=str, default="", help="comma list of modes to run (default: all)")
     a = ap.parse_args()
     import evdr_amd  # noqa: F401
     from evdr_amd import driver
@@ -91,7 +92,10 @@ def main():
         return 1e3 * (time.perf_counter() - t0) / a.steps, last
 
     res = {}
-    for kind in ["call_pattern", "resident", "cached", "fused", "fused_cached"] + (["eager"] if a.eager else []):
+    kinds = ["call_pattern", "resident", "cached", "fused", "fused_cached"] + (["eager"] if a.eager else [])
+    if a.only:
+        kinds = [k for k in kinds if k in a.only.split(",")]
+    for kind in kinds:
         ms, loss = run(kind)
         res[kind] = {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "last_loss": loss}
     print(json.dumps({"metric": "InfoNCE-distillation step time", "unit": "ms/step", "higher_is_better": False,

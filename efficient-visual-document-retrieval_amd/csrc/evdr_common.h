@@ -36,6 +36,26 @@ struct EvdrFwdParams {
     unsigned long long* dbg;    // diagnostic builds only: per-wave cycle sums (null in production)
 };
 
+// Pages per workgroup.  Large problems: enough workgroups for ~6 rounds over the 256 CUs, at most 64 pages each.  Small
+// problems (a training batch against a few hundred pages): a workgroup must stream >= ~64 tiles, otherwise the query load
+// and the ring fill (a few microseconds of latency) dominate the few microseconds of MFMA work per page -- but never
+// fewer workgroups than CUs when that can be avoided.
+static inline int evdr_pages_per_block(int64_t np, int64_t n_qgroups, int64_t ntiles) {
+    const int64_t total = np * n_qgroups;
+    int64_t ppb = total / 1536;
+    if (ppb < 1) ppb = 1;
+    if (ppb > 64) ppb = 64;
+    const int64_t lo = (64 + ntiles - 1) / ntiles;
+    if (ppb < lo) {
+        int64_t fill = (total + 255) / 256;              // pages per workgroup that still gives every CU one workgroup
+        if (fill < 1) fill = 1;
+        ppb = lo < fill ? lo : fill;
+        if (ppb < 1) ppb = 1;
+    }
+    if (ppb > np) ppb = np;
+    return (int)ppb;
+}
+
 // launches (defined in the .hip files; all enqueue on `stream` and return the launch status)
 hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& p, int nplanes, bool want_argmax, hipStream_t stream);
 hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int geom, hipStream_t stream);

@@ -304,10 +304,7 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
         if (variant != 100) return evdr_launch_maxsim_fwd16(p, qw, variant, stream);
     }
     p.n_qgroups = (p.nq + WAVES * qw - 1) / (WAVES * qw);
-    int64_t ppb = ((int64_t)p.np * p.n_qgroups) / 1536;
-    if (ppb < 1) ppb = 1;
-    if (ppb > 64) ppb = 64;
-    p.pages_per_block = (int)ppb;
+    p.pages_per_block = evdr_pages_per_block(p.np, p.n_qgroups, p.ntiles);
     p.n_chunks = (p.np + p.pages_per_block - 1) / p.pages_per_block;
     if (nplanes == 3) {
         return want_argmax ? launch<1, 3, true>(p, stream) : launch<1, 3, false>(p, stream);

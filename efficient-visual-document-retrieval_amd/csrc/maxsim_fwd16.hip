@@ -553,10 +553,7 @@ hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     }
     p.ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     p.n_qgroups = (p.nq + 8 * QW - 1) / (8 * QW);
-    int64_t ppb = ((int64_t)p.np * p.n_qgroups) / 1536;
-    if (ppb < 1) ppb = 1;
-    if (ppb > 64) ppb = 64;
-    p.pages_per_block = (int)ppb;
+    p.pages_per_block = evdr_pages_per_block(p.np, p.n_qgroups, p.ntiles);
     p.n_chunks = (p.np + p.pages_per_block - 1) / p.pages_per_block;
     const int64_t blocks = (int64_t)((p.n_chunks + 7) / 8) * 8 * p.n_qgroups;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(8 * 64), LDS, stream, p);
@@ -576,10 +573,7 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
     }
     p.ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     p.n_qgroups = (p.nq + WAVES * QW - 1) / (WAVES * QW);
-    int64_t ppb = ((int64_t)p.np * p.n_qgroups) / 1536;
-    if (ppb < 1) ppb = 1;
-    if (ppb > 64) ppb = 64;
-    p.pages_per_block = (int)ppb;
+    p.pages_per_block = evdr_pages_per_block(p.np, p.n_qgroups, p.ntiles);
     p.n_chunks = (p.np + p.pages_per_block - 1) / p.pages_per_block;
     const int64_t blocks = (int64_t)((p.n_chunks + 7) / 8) * 8 * p.n_qgroups;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), LDS, stream, p);
