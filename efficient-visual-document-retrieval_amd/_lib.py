@@ -25,6 +25,8 @@ SIGNATURES = {
     "evdr_maxsim_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
     "evdr_maxsim_fwd_prepared": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64, _vp]),
     "evdr_maxsim_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "evdr_maxsim_bwd_q_workspace": (_sz, [_i64, _i64]),
+    "evdr_maxsim_bwd_q": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     "evdr_maxsim_bwd_adamw": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                         _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "evdr_l2norm_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),

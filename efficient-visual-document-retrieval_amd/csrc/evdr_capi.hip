@@ -176,6 +176,32 @@ int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const 
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd launch");
 }
 
+size_t evdr_maxsim_bwd_q_workspace(int64_t np, int64_t lp) {
+    if (np < 0 || lp < 0) return 0;
+    return align_up((size_t)np * ntiles_of(lp) * 4) + align_up((size_t)np * 4);
+}
+
+int evdr_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
+                      float* dQ, int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d, void* workspace,
+                      size_t workspace_bytes, void* hip_stream) {
+    if (int rc = check_common(nq, lq, np, lp)) return rc;
+    if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported", (long long)d);
+    if (nq == 0 || lq == 0) return EVDR_OK;
+    if (!dQ) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_q: null dQ");
+    if (np > 0 && (!g || !P || !argmax)) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_q: null g/P/argmax");
+    if (np > 0 && lp == 0) return fail(EVDR_ERR_SHAPE, "lp == 0");
+    if (!workspace || workspace_bytes < evdr_maxsim_bwd_q_workspace(np, lp))
+        return fail(EVDR_ERR_WORKSPACE, "workspace too small: need %zu bytes", evdr_maxsim_bwd_q_workspace(np, lp));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    uint32_t* tilemask = (uint32_t*)workspace;
+    uint32_t* pageflags = (uint32_t*)((char*)workspace + align_up((size_t)np * ntiles_of(lp) * 4));
+    hipError_t e = hipSuccess;
+    if (np > 0 && (e = evdr_launch_pack_pmask(pmask, np, lp, tilemask, pageflags, stream)) != hipSuccess)
+        return hip_fail(e, "pack_pmask launch");
+    e = evdr_launch_maxsim_bwd_q(g, P, qmask, pageflags, argmax, dQ, nq, lq, np, lp, stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd_q launch");
+}
+
 int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
                           float* x, float* exp_avg, float* exp_avg_sq, int64_t nq, int64_t lq, int64_t np, int64_t lp,
                           int64_t d, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,

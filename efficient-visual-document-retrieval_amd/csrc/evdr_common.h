@@ -69,6 +69,9 @@ hipError_t evdr_launch_maxsim_bwd_adamw(const float* g, const float* Q, const ui
                                         const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq, int64_t nq,
                                         int64_t lq, int64_t np, int64_t lp, float lr, float beta1, float beta2, float eps,
                                         float weight_decay, float bc1, float bc2_sqrt, float eps_norm, hipStream_t stream);
+hipError_t evdr_launch_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint32_t* pageflags,
+                                    const uint16_t* argmax, float* dQ, int64_t nq, int64_t lq, int64_t np, int64_t lp,
+                                    hipStream_t stream);
 hipError_t evdr_launch_l2norm_fwd(const float* x, const uint8_t* rowmask, int64_t rows, float eps, float* y, float* norm,
                                   hipStream_t stream);
 hipError_t evdr_launch_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask, const float* norm, int64_t rows,

@@ -188,6 +188,52 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
     (void)lane;
 }
 
+// ---- gradient w.r.t. the QUERY embeddings:  dQ[q,n,:] = qmask[q,n] * sum_p g[q,p] * has(p) * P[p, argmax[q,p,n], :]
+// One 16-lane group per (query, token); the np (argmax, weight) pairs are fetched 16 at a time, one per lane, and the
+// page rows (512 B, fp32) are gathered four at a time in registers.  HBM/L2-bound: nq*lq*np rows of 512 B.
+__global__ void __launch_bounds__(256) maxsim_bwd_q_kernel(const float* __restrict__ g, const float* __restrict__ P,
+                                                          const uint8_t* __restrict__ qmask,
+                                                          const uint32_t* __restrict__ pageflags,
+                                                          const uint16_t* __restrict__ argmax, float* __restrict__ dQ,
+                                                          int nq, int lq, int np, int lp) {
+    const int sub = threadIdx.x & 15;
+    const int pair = blockIdx.x * 16 + (threadIdx.x >> 4);          // (q, n) handled by this 16-lane group
+    if (pair >= nq * lq) return;
+    const int q = pair / lq, n = pair - q * lq;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    const bool live = (qmask == nullptr) || qmask[pair] != 0;
+    if (live) {
+        for (int p0 = 0; p0 < np; p0 += 16) {
+            const int pl = p0 + sub;                                // this lane's page of the batch
+            int a = 0;
+            float w = 0.f;
+            if (pl < np) {
+                w = (pageflags[pl] & 1u) ? g[(int64_t)q * np + pl] : 0.f;       // has(p) = page has a valid patch
+                a = (int)argmax[((int64_t)q * np + pl) * lq + n];
+            }
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += 4) {
+                f32x4 v0[4], v1[4];
+                float wk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int src = (threadIdx.x & 48) + k0 + u;    // lane k0+u of this 16-lane group (wave-relative)
+                    const int ak = __shfl(a, src);
+                    wk[u] = __shfl(w, src);
+                    const int pk = min(p0 + k0 + u, np - 1);
+                    const float* row = P + ((int64_t)pk * lp + ak) * EVDR_D + sub * 8;
+                    v0[u] = *reinterpret_cast<const f32x4*>(row);
+                    v1[u] = *reinterpret_cast<const f32x4*>(row + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s0 += v0[u] * wk[u]; s1 += v1[u] * wk[u]; }
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(dQ + (int64_t)pair * EVDR_D + sub * 8) = s0;
+    *reinterpret_cast<f32x4*>(dQ + (int64_t)pair * EVDR_D + sub * 8 + 4) = s1;
+}
+
 // ---- l2_normalize (utils/preprocess_data.py:8-9) with an optional per-row mask, forward and backward ---------------
 // y = m * x / (||m*x|| + eps);  one 16-lane group per 128-wide row (8 floats per lane, two 16-B accesses).
 // backward of y = x/(n + eps):  dx = g/(n+eps) - x * (x.g) / (n (n+eps)^2)   (n > 0; the norm's subgradient at 0 is 0)
@@ -347,6 +393,16 @@ hipError_t evdr_launch_maxsim_bwd_adamw(const float* g, const float* Q, const ui
                                         float weight_decay, float bc1, float bc2_sqrt, float eps_norm, hipStream_t stream) {
     AdamArgs ad{x, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, eps_norm};
     return dispatch_bwd<true>(g, Q, qmask, pmask, argmax, nullptr, nq, lq, np, lp, ad, stream);
+}
+
+hipError_t evdr_launch_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint32_t* pageflags,
+                                    const uint16_t* argmax, float* dQ, int64_t nq, int64_t lq, int64_t np, int64_t lp,
+                                    hipStream_t stream) {
+    const int64_t pairs = nq * lq;
+    if (pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(maxsim_bwd_q_kernel, dim3((unsigned)((pairs + 15) / 16)), dim3(256), 0, stream, g, P, qmask, pageflags,
+                       argmax, dQ, (int)nq, (int)lq, (int)np, (int)lp);
+    return hipGetLastError();
 }
 
 hipError_t evdr_launch_l2norm_fwd(const float* x, const uint8_t* rowmask, int64_t rows, float eps, float* y, float* norm,

@@ -39,24 +39,23 @@ def get_torch_device(device: str = "auto") -> str:
 class _MaxSimMasked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Q, P, qmask, pmask):
-        need_dp = ctx.needs_input_grad[1]
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError(
-                "gradient w.r.t. the query embeddings is not implemented (no reference script trains Q); "
-                "detach Q or open an issue")
-        out, arg = ops.maxsim_forward(Q, P, qmask, pmask, want_argmax=need_dp)
-        if need_dp:
-            ctx.save_for_backward(Q.detach(), qmask, pmask, arg)
-            ctx.p_shape = tuple(P.shape)
-            ctx.p_dtype = P.dtype
+        need_dq, need_dp = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        out, arg = ops.maxsim_forward(Q, P, qmask, pmask, want_argmax=need_dp or need_dq)
+        if need_dp or need_dq:
+            ctx.save_for_backward(Q.detach(), P.detach() if need_dq else None, qmask, pmask, arg)
+            ctx.p_shape, ctx.p_dtype, ctx.q_dtype = tuple(P.shape), P.dtype, Q.dtype
         return out
 
     @staticmethod
     def backward(ctx, g):
-        Q, qmask, pmask, arg = ctx.saved_tensors
+        Q, P, qmask, pmask, arg = ctx.saved_tensors
         npg, lp, _ = ctx.p_shape
-        dP = ops.maxsim_backward(g, Q, qmask, pmask, arg, npg, lp)
-        return None, dP.to(ctx.p_dtype), None, None
+        dQ = dP = None
+        if ctx.needs_input_grad[1]:
+            dP = ops.maxsim_backward(g, Q, qmask, pmask, arg, npg, lp).to(ctx.p_dtype)
+        if ctx.needs_input_grad[0]:
+            dQ = ops.maxsim_backward_q(g, P, qmask, pmask, arg, Q.shape[0], Q.shape[1]).to(ctx.q_dtype)
+        return dQ, dP, None, None
 
 
 def score_multi_vector_masked(
@@ -67,7 +66,7 @@ def score_multi_vector_masked(
     chunk_p: int = 128,
 ) -> torch.Tensor:
     """out[q,p] = sum_n qmask[q,n] * any(pmask[p]) * max_m(Q[q,n]·P[p,m] if pmask[p,m] else -1e4), fp32,
-    on the inputs' device, autograd-capable w.r.t. P.  `chunk_p` only bounded the reference's 4-D
+    on the inputs' device, autograd-capable w.r.t. P and Q.  `chunk_p` only bounded the reference's 4-D
     intermediate (evaluator/retrieval.py:187); the fused kernel has none, so it is accepted and ignored."""
     del chunk_p
     return _MaxSimMasked.apply(Q, P, qmask, pmask)

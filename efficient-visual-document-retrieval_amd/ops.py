@@ -221,3 +221,20 @@ def maxsim_backward_adamw(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torc
                                           L.ptr(exp_avg_sq), nq, lq, npg, lp, d, float(lr), float(betas[0]), float(betas[1]),
                                           float(eps), float(weight_decay), int(step), float(l2_eps),
                                           L.current_stream_handle(dev)))
+
+
+def maxsim_backward_q(g: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],
+                      argmax: torch.Tensor, nq: int, lq: int) -> torch.Tensor:
+    """A6, query side: dQ (nq, lq, 128) fp32 from upstream g (nq, np), the fp32 pages and the forward's argmax."""
+    dev = _require_cuda(g, P, argmax)
+    npg, lp, d = P.shape
+    lib = L.load()
+    gc, Pc = g.float().contiguous(), P.float().contiguous()
+    qm = _mask_u8(qmask, (nq, lq), dev)
+    pm = _mask_u8(pmask, (npg, lp), dev)
+    dQ = torch.empty((nq, lq, d), dtype=torch.float32, device=dev)
+    ws = workspace(lib.evdr_maxsim_bwd_q_workspace(npg, lp), dev)
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_maxsim_bwd_q(L.ptr(gc), L.ptr(Pc), L.ptr(qm), L.ptr(pm), L.ptr(argmax), L.ptr(dQ), nq, lq, npg, lp, d,
+                                      L.ptr(ws), ws.numel(), L.current_stream_handle(dev)))
+    return dQ

@@ -94,6 +94,15 @@ int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const 
                     const uint16_t* argmax, float* dP,
                     int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d, void* hip_stream);
 
+/* ---- A6, query side: autograd of A1 w.r.t. Q (the reference's function is differentiable in both arguments) ---------
+ * dQ[q,n,:] = qmask[q,n] * sum_p g[q,p] * has(p) * P[p, argmax[q,p,n], :]
+ * g (nq,np) fp32; P (np,lp,128) fp32 dense; argmax from evdr_maxsim_fwd; dQ (nq,lq,128) fp32 is OVERWRITTEN. */
+size_t evdr_maxsim_bwd_q_workspace(int64_t np, int64_t lp);
+int evdr_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint8_t* pmask,
+                      const uint16_t* argmax, float* dQ,
+                      int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d,
+                      void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* ---- A6 + A4 backward + the optimizer of A7 in ONE launch (mainv2_iter_distill_infonce.py:279,290-291) ---------------
  * Same gather as evdr_maxsim_bwd, but the gradient w.r.t. the normalised pages stays in LDS and the epilogue applies
  * (1) the backward of  y = m x / (||m x|| + l2_eps)  (l2_normalize(Pbar * pmask), utils/preprocess_data.py:8-9) and

@@ -257,6 +257,19 @@ def test_a4_l2norm_kernels(golden, dev):
     assert torch.all(xd.grad.cpu()[~m] == 0) and torch.isfinite(xd.grad).all()
 
 
+@pytest.mark.parametrize("case", ["small_ragged", "lq1", "chunk_tail"])
+def test_a6_query_gradient(dev, ER, case):
+    """d/dQ of the masked scorer (the reference's function is differentiable in Q too) vs autograd through the oracle."""
+    Q, P, qm, pm, g = R.small_case(case)
+    Qo, Po = Q.clone().requires_grad_(True), P.clone().requires_grad_(True)
+    (O.maxsim_masked(Qo, Po, qm, pm) * g).sum().backward()
+    Qd, Pd = Q.to(dev).requires_grad_(True), P.to(dev).requires_grad_(True)
+    (ER.score_multi_vector_masked(Qd, Pd, qm.to(dev), pm.to(dev)) * g.to(dev)).sum().backward()
+    np.testing.assert_allclose(Qd.grad.cpu().numpy(), Qo.grad.numpy(), atol=2e-6)
+    np.testing.assert_allclose(Pd.grad.cpu().numpy(), Po.grad.numpy(), atol=2e-6)
+    assert torch.all(Qd.grad.cpu()[~qm] == 0)                      # masked query tokens get exact zeros
+
+
 # ---- top-k --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,k", [(500, 100), (37, 100), (100, 100), (5000, 10), (100001, 100), (1, 1)])
 def test_topk_vs_oracle(dev, n, k):
