@@ -1,0 +1,78 @@
+// Device-side helpers shared by the MaxSim forward kernels (maxsim_fwd.hip, maxsim_fwd16.hip).
+#pragma once
+#include "evdr_common.h"
+
+namespace evdr {
+
+constexpr int kWaves = 8;                                         // waves per forward workgroup (2 per SIMD)
+constexpr int kTileBytes = EVDR_TILE_PATCHES * EVDR_D * 2;        // 8 KiB: one bf16 plane of one 32-patch tile
+
+__device__ __forceinline__ float neg_inf() { return -__builtin_inff(); }
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [lds_base, lds_base + 1 KiB), lane-linear.
+// Issued as inline asm on purpose: hipcc does not see it, so (a) it cannot put a vmcnt(0) in front of the ds_reads of
+// the ring (it treats a builtin LDS-DMA as an LDS store that may alias them) and (b) the ring's completion is counted
+// by hand with wait_vmcnt<N>().  M0 is written and restored inside the statement (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void lds_dma_16B(const void* gsrc, uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_base)
+        : "memory");
+}
+
+// The same with a wave-uniform 64-bit base in SGPRs and a 32-bit (zero-extended) per-lane byte offset: one VGPR per
+// piece instead of a 64-bit per-lane pointer (the staged kernel issues pieces in the middle of its MFMA block, where
+// VGPRs are scarce).  s_nop 4 covers a base that was just produced by a VALU->SGPR move (§5.7 item 2).
+__device__ __forceinline__ void lds_dma_16B_sbase(const void* sbase, uint32_t voff, uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_base)
+        : "memory");
+}
+
+// counted wait on the vector-memory queue (loads, stores and LDS-DMA count together, in issue order)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Block -> (query group, page chunk).  Blocks b and b+8 share an XCD under round-robin dispatch, so consecutive b>>3
+// walk the query groups of ONE page chunk: its bytes are served from that XCD's L2 (speed only, never correctness).
+struct BlockWork {
+    int qg, pg0, npages;
+    bool valid;
+};
+__device__ __forceinline__ BlockWork block_work(const EvdrFwdParams& p) {
+    const int b = blockIdx.x;
+    const int xi = b >> 3;
+    BlockWork w;
+    w.qg = xi % p.n_qgroups;
+    const int chunk = (xi / p.n_qgroups) * 8 + (b & 7);
+    w.valid = chunk < p.n_chunks;
+    w.pg0 = chunk * p.pages_per_block;
+    w.npages = min(p.pages_per_block, p.np - w.pg0);
+    return w;
+}
+
+}  // namespace evdr
+
+// Host side: queries per workgroup -> launch geometry shared by every forward kernel.
+static inline int64_t evdr_set_geometry(EvdrFwdParams& p, int queries_per_wg) {
+    p.ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
+    p.n_qgroups = (p.nq + queries_per_wg - 1) / queries_per_wg;
+    p.pages_per_block = evdr_pages_per_block(p.np, p.n_qgroups, p.ntiles);
+    p.n_chunks = (p.np + p.pages_per_block - 1) / p.pages_per_block;
+    return (int64_t)((p.n_chunks + 7) / 8) * 8 * p.n_qgroups;     // grid size (whole groups of 8 for the XCD map)
+}

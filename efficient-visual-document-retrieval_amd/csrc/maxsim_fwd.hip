@@ -17,38 +17,14 @@
 //   * NPL = 3 scores fp32 inputs to fp32 accuracy as six bf16 plane products (hi/mid/lo split).
 #include <stdlib.h>
 
-#include "evdr_common.h"
+#include "maxsim_device.h"
 
 namespace {
 
-constexpr int WAVES = 8;
+using namespace evdr;
+constexpr int WAVES = kWaves;
 constexpr int NSTAGE = 3;
-constexpr int TILE_BYTES = EVDR_TILE_PATCHES * EVDR_D * 2;   // 8 KiB, one plane of one 32-patch tile
-
-__device__ __forceinline__ float neg_inf() { return -__builtin_inff(); }
-
-// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [lds_base, lds_base + 1 KiB), lane-linear.
-// Issued as inline asm on purpose: hipcc does not see it, so (a) it cannot put a vmcnt(0) in front of the
-// ds_reads of the ring (it treats a builtin LDS-DMA as an LDS store that may alias them) and (b) the ring's
-// completion is counted by hand with the s_waitcnt vmcnt(N) below.  M0 is written and restored inside the
-// statement (cdna_hip_programming.md §5.7).
-__device__ __forceinline__ void lds_dma_16B(const void* gsrc, uint32_t lds_base) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_base)
-        : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+constexpr int TILE_BYTES = kTileBytes;
 
 // patch row inside a 32-patch tile held by accumulator register `reg` of lane half `h`
 // (C/D map of mfma_f32_32x32x16: row = (reg&3) + 8*(reg>>2) + 4*h)
@@ -73,15 +49,9 @@ __global__ void __launch_bounds__(WAVES * 64) maxsim_fwd_kernel(const EvdrFwdPar
     const int r = lane & 31;      // query token (MFMA column) / patch row for the A fragment
     const int h = lane >> 5;      // lane half
 
-    // ---- block -> (query group, page chunk).  Blocks b and b+8 share an XCD (round-robin dispatch),
-    // so consecutive b>>3 walk the query groups of ONE page chunk: its bytes come from that XCD's L2.
-    const int b = blockIdx.x;
-    const int xi = b >> 3;
-    const int qg = xi % p.n_qgroups;
-    const int chunk = (xi / p.n_qgroups) * 8 + (b & 7);
-    if (chunk >= p.n_chunks) return;
-    const int pg0 = chunk * p.pages_per_block;
-    const int npages = min(p.pages_per_block, p.np - pg0);
+    const BlockWork bw = block_work(p);
+    if (!bw.valid) return;
+    const int qg = bw.qg, pg0 = bw.pg0, npages = bw.npages;
     const int total_tiles = npages * p.ntiles;
     const int nstages = (total_tiles + ST - 1) / ST;
 
@@ -303,9 +273,7 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
         const int variant = e ? atoi(e) : 0;
         if (variant != 100) return evdr_launch_maxsim_fwd16(p, qw, variant, stream);
     }
-    p.n_qgroups = (p.nq + WAVES * qw - 1) / (WAVES * qw);
-    p.pages_per_block = evdr_pages_per_block(p.np, p.n_qgroups, p.ntiles);
-    p.n_chunks = (p.np + p.pages_per_block - 1) / p.pages_per_block;
+    evdr_set_geometry(p, WAVES * qw);
     if (nplanes == 3) {
         return want_argmax ? launch<1, 3, true>(p, stream) : launch<1, 3, false>(p, stream);
     }

@@ -14,49 +14,14 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#include "evdr_common.h"
+#include "maxsim_device.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
 namespace {
 
-constexpr int TILE_BYTES = EVDR_TILE_PATCHES * EVDR_D * 2;      // 8 KiB
-
-__device__ __forceinline__ float neg_inf() { return -__builtin_inff(); }
-
-__device__ __forceinline__ void lds_dma_16B(const void* gsrc, uint32_t lds_base) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_base)
-        : "memory");
-}
-
-// Same LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: one VGPR per piece instead of
-// a 64-bit per-lane pointer (the staged kernel issues pieces in the middle of its MFMA block, where VGPRs are scarce).
-// s_nop 4 covers a base that was just produced by a VALU->SGPR move (cdna_hip_programming.md §5.7 item 2).
-__device__ __forceinline__ void lds_dma_16B_sbase(const void* sbase, uint32_t voff, uint32_t lds_base) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 4\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_base)
-        : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+using namespace evdr;
+constexpr int TILE_BYTES = kTileBytes;
 
 // Flat per-tile schedule: WAVES waves per workgroup, ST 32-patch tiles per ring stage, NSTAGE ring slots over the
 // block's flat tile stream (stages ignore page boundaries).  Used for short pages (< 8 tiles, e.g. the compressed
@@ -73,13 +38,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
     const int c = lane & 15;
     const int g = lane >> 4;
 
-    const int b = blockIdx.x;
-    const int xi = b >> 3;
-    const int qg = xi % p.n_qgroups;
-    const int chunk = (xi / p.n_qgroups) * 8 + (b & 7);
-    if (chunk >= p.n_chunks) return;
-    const int pg0 = chunk * p.pages_per_block;
-    const int npages = min(p.pages_per_block, p.np - pg0);
+    const BlockWork bw = block_work(p);
+    if (!bw.valid) return;
+    const int qg = bw.qg, pg0 = bw.pg0, npages = bw.npages;
     const int total_tiles = npages * p.ntiles;
     const int nstages = (total_tiles + ST - 1) / ST;
 
@@ -291,13 +252,9 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
     const int c = lane & 15;
     const int g = lane >> 4;
 
-    const int b = blockIdx.x;
-    const int xi = b >> 3;
-    const int qg = xi % p.n_qgroups;
-    const int chunk = (xi / p.n_qgroups) * 8 + (b & 7);
-    if (chunk >= p.n_chunks) return;
-    const int pg0 = chunk * p.pages_per_block;
-    const int npages = min(p.pages_per_block, p.np - pg0);
+    const BlockWork bw = block_work(p);
+    if (!bw.valid) return;
+    const int qg = bw.qg, pg0 = bw.pg0, npages = bw.npages;
     const int spp = (p.ntiles + ST - 1) / ST;             // stages per page
     const int nstages = npages * spp;
     unsigned long long d_t0 = 0, d_pro = 0, d_bar = 0, d_ref = 0, d_fast = 0, d_gen = 0, d_fin = 0, d_a = 0;
@@ -551,11 +508,7 @@ hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    p.ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
-    p.n_qgroups = (p.nq + 8 * QW - 1) / (8 * QW);
-    p.pages_per_block = evdr_pages_per_block(p.np, p.n_qgroups, p.ntiles);
-    p.n_chunks = (p.np + p.pages_per_block - 1) / p.pages_per_block;
-    const int64_t blocks = (int64_t)((p.n_chunks + 7) / 8) * 8 * p.n_qgroups;
+    const int64_t blocks = evdr_set_geometry(p, 8 * QW);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(8 * 64), LDS, stream, p);
     return hipGetLastError();
 }
@@ -571,11 +524,7 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    p.ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
-    p.n_qgroups = (p.nq + WAVES * QW - 1) / (WAVES * QW);
-    p.pages_per_block = evdr_pages_per_block(p.np, p.n_qgroups, p.ntiles);
-    p.n_chunks = (p.np + p.pages_per_block - 1) / p.pages_per_block;
-    const int64_t blocks = (int64_t)((p.n_chunks + 7) / 8) * 8 * p.n_qgroups;
+    const int64_t blocks = evdr_set_geometry(p, WAVES * QW);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), LDS, stream, p);
     return hipGetLastError();
 }
