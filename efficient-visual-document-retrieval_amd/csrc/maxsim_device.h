@@ -48,6 +48,43 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---- cross-lane reductions for the page epilogue, at VALU speed (no LDS round trips) ------------------------------
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / 32-lane halves between TWO registers
+// (measured lane maps, a = vdst, b = src:  16: a' = [a.row0, b.row0, a.row2, b.row2], b' = [a.row1, b.row1, a.row3, b.row3];
+//  32: a' = [a.lo, b.lo], b' = [a.hi, b.hi]).  Fed two copies of one value, a' and b' together give every lane its own and
+// its partner row's / half's value.  Inline asm with two "+v" operands: the copies are then necessarily in different
+// registers (a register swapped with itself is a no-op) and both results are unambiguous -- the builtin form returned
+// the first result twice when both inputs carried the same value (hipcc 7.2).  The two v_nop are the VALU-write ->
+// permlane-read wait states, which hipcc does not insert inside an asm string (cdna_hip_programming.md T21).
+__device__ __forceinline__ void swap16(float& a, float& b) {
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xhalf_max(float v) {           // max over {l, l^32}, in every lane
+    float a = v, b = v;
+    swap32(a, b);
+    return __builtin_fmaxf(a, b);
+}
+__device__ __forceinline__ float xgroup_max(float v) {          // max over the four lane groups {l, l^16, l^32, l^48}
+    float a = v, b = v;
+    swap16(a, b);
+    return xhalf_max(__builtin_fmaxf(a, b));
+}
+__device__ __forceinline__ float row16_sum(float v) {           // sum over the 16 lanes of a DPP row, in every lane
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row32_sum(float v) {           // sum over the 32 lanes of a half, in every lane
+    float a = row16_sum(v), b = a;
+    swap16(a, b);
+    return a + b;
+}
+
 // Block -> (query group, page chunk).  Blocks b and b+8 share an XCD under round-robin dispatch, so consecutive b>>3
 // walk the query groups of ONE page chunk: its bytes are served from that XCD's L2 (speed only, never correctness).
 struct BlockWork {

@@ -216,12 +216,7 @@ __global__ void __launch_bounds__(WAVES * 64) maxsim_fwd_kernel(const EvdrFwdPar
                             } else {
                                 v = __builtin_fmaxf(v, o);
                             }
-                            float c = v * has * qwt[j];
-                            c += __shfl_xor(c, 16);
-                            c += __shfl_xor(c, 8);
-                            c += __shfl_xor(c, 4);
-                            c += __shfl_xor(c, 2);
-                            c += __shfl_xor(c, 1);
+                            const float c = row32_sum(v * has * qwt[j]);
                             if (lane == 0 && q0 + j < p.nq) {
                                 float* o = p.out + (int64_t)(q0 + j) * p.out_stride + page;
                                 if (p.accumulate) atomicAdd(o, c);     // later 32-token slice: no-return atomic

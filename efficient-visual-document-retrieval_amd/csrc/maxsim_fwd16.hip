@@ -191,15 +191,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
                             float cs = 0.f;
 #pragma unroll
                             for (int t = 0; t < 2; ++t) {
-                                float v = run[j][t];
-                                v = __builtin_fmaxf(v, __shfl_xor(v, 16));
-                                v = __builtin_fmaxf(v, __shfl_xor(v, 32));
-                                cs += v * has * qwt[j][t];
+                                cs += xgroup_max(run[j][t]) * has * qwt[j][t];
                             }
-                            cs += __shfl_xor(cs, 8);
-                            cs += __shfl_xor(cs, 4);
-                            cs += __shfl_xor(cs, 2);
-                            cs += __shfl_xor(cs, 1);
+                            cs = row16_sum(cs);
                             if (lane == 0 && q0 + j < p.nq) {
                                 float* o = p.out + (int64_t)(q0 + j) * p.out_stride + page;
                                 if (p.accumulate) atomicAdd(o, cs);
@@ -470,15 +464,9 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
                 float cs = 0.f;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    float v = run[j][t];
-                    v = __builtin_fmaxf(v, __shfl_xor(v, 16));
-                    v = __builtin_fmaxf(v, __shfl_xor(v, 32));
-                    cs += v * has * qwt[j][t];
+                    cs += xgroup_max(run[j][t]) * has * qwt[j][t];
                 }
-                cs += __shfl_xor(cs, 8);
-                cs += __shfl_xor(cs, 4);
-                cs += __shfl_xor(cs, 2);
-                cs += __shfl_xor(cs, 1);
+                cs = row16_sum(cs);
                 if (lane == 0 && q0 + j < p.nq) {
                     float* o = p.out + (int64_t)(q0 + j) * p.out_stride + page;
                     if (p.accumulate) atomicAdd(o, cs);
