@@ -215,8 +215,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
 
 
 // ---- page-aligned stages, straight-line fast stage ---------------------------------------------------------------
-// Ring stages are aligned to pages: a page of T tiles is ceil(T/4) stages, the last one short (a 1030-patch page = 8
-// stages of 4 full tiles + 1 stage holding the 6-patch tail tile).  A stage whose 4 tiles are all valid and belong
+// Ring stages are aligned to pages: a page of T tiles is ceil(T/ST) stages, the last one short -- or, when T = k*ST + 1,
+// k stages whose last one carries the extra tile in a ring slot of ST + 1 tiles (a 1030-patch page = 3 stages of 8 full
+// tiles + 1 stage of 8 full tiles and the 6-patch tail tile).  A stage whose 4 tiles are all valid and belong
 // to one page -- 32 of the 33 tiles of such a page -- runs as ONE basic block: 8 half-tile steps x 8 chains x 4 MFMAs
 // per wave with no branch, no scalar load and no wait other than the LDS counters in between, so the compiler overlaps
 // every v_max3 epilogue and every ds_read with MFMAs of the following chains (the per-tile schedule lost ~28 % of the
@@ -237,8 +238,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 template <int QW, int ST, int NSTAGE, bool DIAG = false, bool BAL = false>
 __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
     constexpr int WAVES = 8;
-    constexpr int STAGE_BYTES = ST * TILE_BYTES;
+    constexpr int SLOT_TILES = ST + 1;                    // a ring slot holds one tile more than a stage's ST ...
+    constexpr int STAGE_BYTES = SLOT_TILES * TILE_BYTES;
     constexpr int G = ST * 8 / WAVES;
+    static_assert(G * WAVES == ST * 8 && WAVES == 8, "one LDS-DMA piece of the extra tile per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -249,7 +252,10 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
     const BlockWork bw = block_work(p);
     if (!bw.valid) return;
     const int qg = bw.qg, pg0 = bw.pg0, npages = bw.npages;
-    const int spp = (p.ntiles + ST - 1) / ST;             // stages per page
+    // ... so that a page of k*ST + 1 tiles (1030 patches = 4*8 + 1) is k stages, the last one carrying the tail tile,
+    // instead of k + 1 stages with a whole barrier / refill round for one 6-patch tile
+    const bool ext = (p.ntiles % ST == 1) && (p.ntiles > ST);
+    const int spp = ext ? p.ntiles / ST : (p.ntiles + ST - 1) / ST;      // stages per page
     const int nstages = npages * spp;
     unsigned long long d_t0 = 0, d_pro = 0, d_bar = 0, d_ref = 0, d_fast = 0, d_gen = 0, d_fin = 0, d_a = 0;
     if constexpr (DIAG) d_t0 = stamp();
@@ -306,9 +312,21 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
             voff = swz[piece & 3] + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
         lds_dma_16B_sbase(sb, voff, __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + tis * TILE_BYTES + piece * 1024));
     };
+    // the extra (ST-th) tile of an extended last stage: piece `wave` of that tile, one per wave, always clamped
+    auto issue_extra = [&](int S, int slot) {
+        const int pgi = S / spp;
+        const int k = S - pgi * spp;
+        if (!(ext && k == spp - 1)) return;
+        const int row0 = (k * ST + ST) * EVDR_TILE_PATCHES + wave * 4;
+        const int rbase = min(row0, p.lp - 1);
+        const uint16_t* sb = p.P + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
+        const uint32_t voff = swz[wave & 3] + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
+        lds_dma_16B_sbase(sb, voff, __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + ST * TILE_BYTES + wave * 1024));
+    };
     auto issue_stage = [&](int S, int slot) {
 #pragma unroll
         for (int i = 0; i < G; ++i) issue_piece(S, slot, i, std::false_type{});
+        issue_extra(S, slot);
     };
     constexpr bool SPREAD = (NSTAGE == 2) && (G == ST);      // one piece per tile of the straight-line block
 
@@ -385,6 +403,26 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
             if (refill && !spread) issue_stage(S + NSTAGE - 1, nslot);
             if constexpr (DIAG) { const unsigned long long t = stamp(); d_ref += t - d_a; d_a = t; }
             const char* sbase = a_lane + slot * STAGE_BYTES;
+            const int nt = (k == spp - 1) ? p.ntiles - t0 : ST;          // tiles in this stage (ST + 1 in an extended last stage)
+            // ---- generic path: one tile, per 16-patch half, masks from the valid length or the mask words
+            auto generic_tile = [&](int tis) {
+                const int tip = t0 + tis;
+                uint32_t tm;
+                if (vlen >= 0) {
+                    const int rem = vlen - tip * EVDR_TILE_PATCHES;
+                    tm = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+                } else {
+                    tm = tilemask_c[(int64_t)page * p.ntiles + tip];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t bits = (tm >> (16 * u)) & 0xFFFFu;
+                    if (bits == 0u) continue;
+                    bf16x8 a[4];
+                    load_half(a, sbase, tis, u);
+                    if (bits == 0xFFFFu) chains_full(a); else chains_masked(a, bits);
+                }
+            };
             if (active) {
                 if (fast) {
                     // ---- fast stage: ST all-valid tiles of one page, one basic block (two instances: with / without refill)
@@ -428,28 +466,11 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
                     } else {
                         if (spread) fast_block(std::true_type{}, std::false_type{}); else fast_block(std::false_type{}, std::false_type{});
                     }
+                    if (spread) issue_extra(S + 1, nslot);               // the next stage's tail-tile piece, after the block
                     if constexpr (DIAG) { const unsigned long long t = stamp(); d_fast += t - d_a; d_a = t; }
+                    if (nt > ST) generic_tile(ST);                       // tail tile riding in this (last) stage
                 } else {
-                    // ---- generic stage: per tile, per 16-patch half
-                    for (int tis = 0; tis < ST; ++tis) {
-                        const int tip = t0 + tis;
-                        if (tip >= p.ntiles) break;
-                        uint32_t tm;
-                        if (vlen >= 0) {
-                            const int rem = vlen - tip * EVDR_TILE_PATCHES;
-                            tm = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
-                        } else {
-                            tm = tilemask_c[(int64_t)page * p.ntiles + tip];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const uint32_t bits = (tm >> (16 * u)) & 0xFFFFu;
-                            if (bits == 0u) continue;
-                            bf16x8 a[4];
-                            load_half(a, sbase, tis, u);
-                            if (bits == 0xFFFFu) chains_full(a); else chains_masked(a, bits);
-                        }
-                    }
+                    for (int tis = 0; tis < nt; ++tis) generic_tile(tis);
                 }
             }
             if constexpr (DIAG) { if (!fast) { const unsigned long long t = stamp(); d_gen += t - d_a; d_a = t; } }
@@ -488,7 +509,7 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
 template <int QW, int ST, int NSTAGE, bool DIAG = false, bool BAL = false>
 hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
-    constexpr int LDS = NSTAGE * ST * TILE_BYTES;
+    constexpr int LDS = NSTAGE * (ST + 1) * TILE_BYTES;
     auto kern = maxsim_fwd16s_kernel<QW, ST, NSTAGE, DIAG, BAL>;
     static bool attr_done = false;
     if (!attr_done) {
