@@ -56,6 +56,19 @@ static inline int evdr_pages_per_block(int64_t np, int64_t n_qgroups, int64_t nt
     return (int)ppb;
 }
 
+// The dynamic-LDS limit of a kernel is a per-(function, device) attribute: remember the devices it was raised on, so that
+// one process driving several GPUs (torch.cuda.set_device between calls) gets it on each of them.
+static inline hipError_t evdr_ensure_dyn_lds(const void* kern, int bytes, uint64_t& devs_done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (devs_done & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) devs_done |= bit;
+    return e;
+}
+
 // launches (defined in the .hip files; all enqueue on `stream` and return the launch status)
 hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& p, int nplanes, bool want_argmax, hipStream_t stream);
 hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int geom, hipStream_t stream);

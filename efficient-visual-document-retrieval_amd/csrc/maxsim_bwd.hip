@@ -358,12 +358,8 @@ static hipError_t launch_bwd(const float* g, const float* Q, const uint8_t* qmas
                              float* dP, int64_t nq, int64_t lq, int64_t np, int64_t lp, const AdamArgs& ad, hipStream_t stream) {
     constexpr int LDS = BW_ROWS * EVDR_D * 4 + CHUNK * 8 + BW_ROWS * 12;
     auto kern = maxsim_bwd_kernel<BW_ROWS, CHUNK, FUSED>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static uint64_t attr_devs = 0;
+    if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     dim3 grid((unsigned)np, (unsigned)((lp + BW_ROWS - 1) / BW_ROWS));
     hipLaunchKernelGGL(kern, grid, dim3(BW_THREADS), LDS, stream, g, Q, qmask, pmask, argmax, dP, (int)nq, (int)lq, (int)np,
                        (int)lp, ad);

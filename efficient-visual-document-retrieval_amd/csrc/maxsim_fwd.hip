@@ -240,12 +240,8 @@ hipError_t launch(const EvdrFwdParams& p, hipStream_t stream) {
     constexpr int ST = (NPL == 1) ? 4 : 2;
     constexpr int LDS = NSTAGE * ST * NPL * TILE_BYTES;
     auto kern = maxsim_fwd_kernel<QW, NPL, ARGMAX>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static uint64_t attr_devs = 0;
+    if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = (int64_t)((p.n_chunks + 7) / 8) * 8 * p.n_qgroups;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), LDS, stream, p);
     return hipGetLastError();

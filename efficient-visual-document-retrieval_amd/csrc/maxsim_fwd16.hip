@@ -511,12 +511,8 @@ hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
     constexpr int LDS = NSTAGE * (ST + 1) * TILE_BYTES;
     auto kern = maxsim_fwd16s_kernel<QW, ST, NSTAGE, DIAG, BAL>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static uint64_t attr_devs = 0;
+    if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, 8 * QW);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(8 * 64), LDS, stream, p);
     return hipGetLastError();
@@ -527,12 +523,8 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
     constexpr int LDS = NSTAGE * ST * TILE_BYTES;
     auto kern = maxsim_fwd16_kernel<QW, WAVES, ST, NSTAGE>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static uint64_t attr_devs = 0;
+    if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, WAVES * QW);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), LDS, stream, p);
     return hipGetLastError();
