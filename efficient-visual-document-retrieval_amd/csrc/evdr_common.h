@@ -36,24 +36,32 @@ struct EvdrFwdParams {
     unsigned long long* dbg;    // diagnostic builds only: per-wave cycle sums (null in production)
 };
 
-// Pages per workgroup.  Large problems: enough workgroups for ~6 rounds over the 256 CUs, at most 64 pages each.  Small
-// problems (a training batch against a few hundred pages): a workgroup must stream >= ~64 tiles, otherwise the query load
-// and the ring fill (a few microseconds of latency) dominate the few microseconds of MFMA work per page -- but never
-// fewer workgroups than CUs when that can be avoided.
+// Pages per workgroup.  Workgroups are equal-sized and one fits per CU, so a launch runs in ceil(workgroups / 256) rounds
+// of `ppb` pages each plus a fixed cost per workgroup (query load + ring fill, worth about 16 tiles of MFMA work).
+// Pick the ppb in [lo, 64] that minimises rounds x (ppb + fixed): this avoids e.g. 1539 workgroups = 6 full rounds + a
+// seventh for 3 workgroups.  lo: a workgroup should stream >= ~64 tiles, otherwise the fixed cost dominates -- unless
+// that would leave CUs without any workgroup.  Many rounds (>= 24) need no tuning: take <= 64 pages, ~6+ rounds.
 static inline int evdr_pages_per_block(int64_t np, int64_t n_qgroups, int64_t ntiles) {
     const int64_t total = np * n_qgroups;
-    int64_t ppb = total / 1536;
-    if (ppb < 1) ppb = 1;
-    if (ppb > 64) ppb = 64;
-    const int64_t lo = (64 + ntiles - 1) / ntiles;
-    if (ppb < lo) {
-        int64_t fill = (total + 255) / 256;              // pages per workgroup that still gives every CU one workgroup
-        if (fill < 1) fill = 1;
-        ppb = lo < fill ? lo : fill;
-        if (ppb < 1) ppb = 1;
+    int64_t lo = (64 + ntiles - 1) / ntiles;
+    const int64_t fill = (total + 255) / 256;            // pages per workgroup that still gives every CU one workgroup
+    if (lo > fill) lo = fill;
+    if (lo < 1) lo = 1;
+    int64_t hi = total / 1536;                           // ~6 rounds
+    if (hi > 64) hi = 64;
+    if (hi < lo) hi = lo;
+    if (hi > np) hi = np;
+    if (lo > hi) lo = hi;
+    if (total / (256 * hi) >= 24) return (int)hi;        // tail round <= 4 % whatever the choice
+    int64_t best = hi;
+    double best_cost = 1e30;
+    for (int64_t ppb = np < 64 ? np : 64; ppb >= lo; --ppb) {
+        const int64_t wgs = ((np + ppb - 1) / ppb) * n_qgroups;
+        const int64_t rounds = (wgs + 255) / 256;
+        const double cost = (double)rounds * ((double)ppb + 16.0 / (double)ntiles);
+        if (cost < best_cost) { best_cost = cost; best = ppb; }   // ties: the larger ppb (fewer workgroups)
     }
-    if (ppb > np) ppb = np;
-    return (int)ppb;
+    return (int)best;
 }
 
 // The dynamic-LDS limit of a kernel is a per-(function, device) attribute: remember the devices it was raised on, so that

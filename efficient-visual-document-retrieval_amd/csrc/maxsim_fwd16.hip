@@ -235,8 +235,8 @@ __device__ __forceinline__ unsigned long long stamp() {
     return t;
 }
 
-template <int QW, int ST, int NSTAGE, bool DIAG = false, bool BAL = false>
-__global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
+template <int QW, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
+__global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
     constexpr int WAVES = 8;
     constexpr int SLOT_TILES = ST + 1;                    // a ring slot holds one tile more than a stage's ST ...
     constexpr int STAGE_BYTES = SLOT_TILES * TILE_BYTES;
@@ -506,11 +506,11 @@ __global__ void __launch_bounds__(8 * 64, 2) maxsim_fwd16s_kernel(const EvdrFwdP
     }
 }
 
-template <int QW, int ST, int NSTAGE, bool DIAG = false, bool BAL = false>
+template <int QW, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
 hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
     constexpr int LDS = NSTAGE * (ST + 1) * TILE_BYTES;
-    auto kern = maxsim_fwd16s_kernel<QW, ST, NSTAGE, DIAG, BAL>;
+    auto kern = maxsim_fwd16s_kernel<QW, ST, NSTAGE, DIAG, BAL, OCC>;
     static uint64_t attr_devs = 0;
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, 8 * QW);
@@ -544,10 +544,17 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int geom, hi
         return geom == 50 ? launch16s<4, 8, 2, true, false>(pd, stream) : launch16s<4, 8, 2, true, true>(pd, stream);
     }
     if (geom == 2 && ntiles >= 8 && qw == 4) return launch16s<4, 8, 2, false, false>(p, stream);   // A/B: no priority schedule
-    if (geom != 1 && ntiles >= 8) {
+    if (geom != 1 && geom != 3 && !(geom == 4 && qw == 1) && ntiles >= 8) {
         if (qw == 4) return launch16s<4, 8, 2, false, true>(p, stream);
         if (qw == 2) return launch16s<2, 8, 2, false, true>(p, stream);
         return launch16s<1, 8, 2, false, true>(p, stream);
+    }
+    if (geom == 4 && ntiles >= 8 && qw == 1)            // A/B: 4-tile stages, two workgroups per CU (80 KiB of LDS each)
+        return launch16s<1, 4, 2, false, false, 4>(p, stream);
+    if (geom == 3) {                                    // A/B: deeper flat ring (3 of 4 stages in flight)
+        if (qw == 4) return launch16<4, 8, 4, 4>(p, stream);
+        if (qw == 2) return launch16<2, 8, 4, 4>(p, stream);
+        return launch16<1, 8, 4, 4>(p, stream);
     }
     if (qw == 4) return launch16<4, 8, 4, 3>(p, stream);
     if (qw == 2) return launch16<2, 8, 4, 3>(p, stream);
