@@ -100,7 +100,7 @@ def main():
         res[kind] = {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "last_loss": loss}
     print(json.dumps({"metric": "InfoNCE-distillation step time", "unit": "ms/step", "higher_is_better": False,
                       "config": {"workload": "mainv2_iter_distill_infonce step (BASELINE.json configs[4])", "pages": N,
-                                 "batch_queries": B, "teacher_patches": Lt, "student_patches": Ls, "dtype": "fp32 (bf16x3 split MFMA)"},
+                                 "batch_queries": B, "teacher_patches": Lt, "student_patches": Ls, "dtype": "fp32 (fp16 hi/lo split MFMA)"},
                       "results": res}))
 
 

@@ -20,10 +20,11 @@ SIGNATURES = {
     "evdr_version": (C.c_int, []),
     "evdr_last_error": (C.c_char_p, []),
     "evdr_pack_pmask": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
-    "evdr_split_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "evdr_split_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "evdr_maxsim_fwd_workspace": (_sz, [_i64, _i64, _i64, _i64, C.c_int]),
     "evdr_maxsim_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
-    "evdr_maxsim_fwd_prepared": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64, _vp]),
+    "evdr_maxsim_fwd_prepared": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64,
+                                           _vp, _vp, _vp]),
     "evdr_maxsim_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     "evdr_maxsim_bwd_q_workspace": (_sz, [_i64, _i64]),
     "evdr_maxsim_bwd_q": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
@@ -33,7 +34,8 @@ SIGNATURES = {
     "evdr_l2norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
     "evdr_topk": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, C.c_int, _vp, _vp, _vp]),
     "evdr_maxsim_topk_workspace": (_sz, [_i64, _i64]),
-    "evdr_maxsim_topk": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64, _i32, C.c_int, _vp, _vp, _vp, _sz, _vp]),
+    "evdr_maxsim_topk": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64, _vp, _vp, _i32, C.c_int,
+                                   _vp, _vp, _vp, _sz, _vp]),
     "evdr_infonce_distill_fwd_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
 }
 

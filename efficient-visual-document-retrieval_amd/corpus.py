@@ -1,8 +1,8 @@
 """Resident page corpus, per-shard top-k and the multi-GPU merge (SURVEY §8(d),(e); BASELINE.json config 4).
 
 None of this exists in the reference (single process, whole corpus on one device, ranking on the host from a
-dict of every score).  MI355X layout: the corpus is stored page-major in HBM as bf16 planes (1 plane = a bf16
-corpus, 3 planes = an fp32 corpus split hi/mid/lo), 263 680 B per 1030-patch page and plane, plus 4 B per
+dict of every score).  MI355X layout: the corpus is stored page-major in HBM as 16-bit planes (1 plane = a bf16
+corpus, 2 planes = an fp32 corpus split into fp16 hi/lo), 263 680 B per 1030-patch page and plane, plus 4 B per
 32-patch tile of packed mask; it is prepared once and stays resident (100 k pages = 26.4 GB of 288 GB).
 Pages shard contiguously over ranks; queries are replicated; each rank scores its shard and keeps k
 candidates per query; ONE all-gather of (nq, 2k) int32 words per rank (scores bit-cast next to global page
@@ -28,31 +28,43 @@ def shard_range(n_pages: int, rank: int, world: int) -> Tuple[int, int]:
 class PageCorpus:
     """One rank's prepared, HBM-resident slice of the page corpus."""
 
-    def __init__(self, planes: torch.Tensor, tilemask: torch.Tensor, pageflags: torch.Tensor, idx_base: int = 0):
-        if planes.dim() != 4 or planes.dtype != torch.bfloat16 or planes.shape[0] not in (1, 3) or planes.shape[-1] != ops.D:
-            raise RuntimeError("planes must be (1|3, np, lp, 128) bf16")
-        self.planes = planes.contiguous()
+    def __init__(self, planes: torch.Tensor, tilemask: torch.Tensor, pageflags: torch.Tensor, idx_base: int = 0,
+                 amax: Optional[torch.Tensor] = None):
+        ok = planes.dim() == 4 and planes.shape[-1] == ops.D and (
+            (planes.dtype == torch.bfloat16 and planes.shape[0] == 1) or
+            (planes.dtype == torch.float16 and planes.shape[0] == 2 and amax is not None))
+        if not ok:
+            raise RuntimeError("planes must be (1, np, lp, 128) bf16, or (2, np, lp, 128) fp16 hi/lo with their absmax word")
+        self.planes = planes
+        self.amax = amax                     # absmax word of the fp32 tensor the fp16 planes were split from
         self.tilemask = tilemask
         self.pageflags = pageflags
         self.idx_base = int(idx_base)
         self.nplanes, self.n_pages, self.lp, _ = planes.shape
+        if planes.stride(3) != 1 or planes.stride(2) != ops.D:
+            raise RuntimeError("planes must be dense in their last two dims")
+        self.p_stride, self.p_plane_stride = int(planes.stride(1)), int(planes.stride(0))
         self.device = planes.device
 
     @classmethod
     def from_tensor(cls, P: torch.Tensor, pmask: Optional[torch.Tensor] = None, idx_base: int = 0) -> "PageCorpus":
-        """P (np, lp, 128): bf16 is kept as one plane, anything else is treated as fp32 and split into 3."""
+        """P (np, lp, 128): bf16 is kept as one plane, anything else is treated as fp32 and split into fp16 hi/lo."""
         dev = ops._require_cuda(P)
         npg, lp, _ = P.shape
-        planes = P.contiguous()[None] if P.dtype == torch.bfloat16 else ops.split_f32(P)
+        planes, amax = (P.contiguous()[None], None) if P.dtype == torch.bfloat16 else ops.split_f32(P)
         tilemask, pageflags = ops.pack_pmask(pmask, npg, lp, dev)
-        return cls(planes, tilemask, pageflags, idx_base)
+        return cls(planes, tilemask, pageflags, idx_base, amax)
 
-    def _query_planes(self, Q: torch.Tensor) -> torch.Tensor:
+    def shard(self, lo: int, hi: int) -> "PageCorpus":
+        """Pages [lo, hi) of this corpus as a corpus of their own (views, nothing copied)."""
+        return PageCorpus(self.planes[:, lo:hi], self.tilemask[lo:hi], self.pageflags[lo:hi], self.idx_base + lo, self.amax)
+
+    def _query_planes(self, Q: torch.Tensor) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         if self.nplanes == 1:
             if Q.dtype != torch.bfloat16:
                 raise RuntimeError("bf16 corpus needs bf16 queries (round them explicitly with .bfloat16(), or "
                                    "build the corpus from fp32 to score at fp32 accuracy)")
-            return Q.contiguous()[None]
+            return Q.contiguous()[None], None
         return ops.split_f32(Q)
 
     def score(self, Q: torch.Tensor, qmask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
@@ -66,14 +78,14 @@ class PageCorpus:
         view = out[:, out_col:out_col + self.n_pages]
         if nq == 0 or self.n_pages == 0:
             return view
-        qp = self._query_planes(Q)
+        qp, qamax = self._query_planes(Q)
         qm = ops._mask_u8(qmask, (nq, lq), dev)
         lib = L.load()
         with torch.cuda.device(dev):
             L.check(lib.evdr_maxsim_fwd_prepared(
                 L.ptr(qp), L.ptr(self.planes), L.ptr(qm), L.ptr(self.tilemask), L.ptr(self.pageflags),
                 view.data_ptr(), out.stride(0), None, nq, lq, self.n_pages, self.lp, self.nplanes,
-                self.lp * ops.D, self.n_pages * self.lp * ops.D, L.current_stream_handle(dev)))
+                self.p_stride, self.p_plane_stride, L.ptr(qamax), L.ptr(self.amax), L.current_stream_handle(dev)))
         return view
 
     def topk(self, Q: torch.Tensor, qmask: Optional[torch.Tensor], k: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -88,15 +100,15 @@ class PageCorpus:
             ts.fill_(float("-inf"))
             ti.fill_(-1)
             return ts, ti
-        qp = self._query_planes(Q)
+        qp, qamax = self._query_planes(Q)
         qm = ops._mask_u8(qmask, (nq, lq), dev)
         lib = L.load()
         ws = ops.workspace(lib.evdr_maxsim_topk_workspace(nq, self.n_pages), dev)
         with torch.cuda.device(dev):
             L.check(lib.evdr_maxsim_topk(
                 L.ptr(qp), L.ptr(self.planes), L.ptr(qm), L.ptr(self.tilemask), L.ptr(self.pageflags),
-                nq, lq, self.n_pages, self.lp, self.nplanes, self.lp * ops.D, self.n_pages * self.lp * ops.D,
-                self.idx_base, k, L.ptr(ts), L.ptr(ti), L.ptr(ws), ws.numel(), L.current_stream_handle(dev)))
+                nq, lq, self.n_pages, self.lp, self.nplanes, self.p_stride, self.p_plane_stride,
+                L.ptr(qamax), L.ptr(self.amax), self.idx_base, k, L.ptr(ts), L.ptr(ti), L.ptr(ws), ws.numel(), L.current_stream_handle(dev)))
         return ts, ti
 
 

@@ -27,7 +27,7 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int64_t ntiles_of(int64_t lp) { return (lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES; }
 
 struct FwdWorkspace {
-    size_t tilemask_off, pageflags_off, qplanes_off, pplanes_off, total;
+    size_t tilemask_off, pageflags_off, amax_off, qplanes_off, pplanes_off, total;
 };
 
 FwdWorkspace carve_fwd(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype) {
@@ -37,10 +37,12 @@ FwdWorkspace carve_fwd(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype
     off = align_up(off + (size_t)np * ntiles_of(lp) * 4);
     w.pageflags_off = off;
     off = align_up(off + (size_t)np * 4);
+    w.amax_off = off;                                   // [0] = Q's absmax bits, [1] = P's
+    if (dtype == EVDR_F32) off = align_up(off + 2 * sizeof(uint32_t));
     w.qplanes_off = off;
-    if (dtype == EVDR_F32) off = align_up(off + (size_t)3 * nq * lq * EVDR_D * 2);
+    if (dtype == EVDR_F32) off = align_up(off + (size_t)2 * nq * lq * EVDR_D * 2);
     w.pplanes_off = off;
-    if (dtype == EVDR_F32) off = align_up(off + (size_t)3 * np * lp * EVDR_D * 2);
+    if (dtype == EVDR_F32) off = align_up(off + (size_t)2 * np * lp * EVDR_D * 2);
     w.total = off;
     return w;
 }
@@ -57,7 +59,7 @@ int check_common(int64_t nq, int64_t lq, int64_t np, int64_t lp) {
 int run_fwd(const uint16_t* Qp, int64_t q_stride, int64_t q_plane_stride, const uint16_t* Pp, int64_t p_stride,
             int64_t p_plane_stride, const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
             float* out, int64_t out_stride, uint16_t* argmax, int64_t nq, int64_t lq, int64_t np, int64_t lp,
-            int nplanes, hipStream_t stream) {
+            int nplanes, const uint32_t* q_amax, const uint32_t* p_amax, hipStream_t stream) {
     for (int64_t tok0 = 0; tok0 < lq; tok0 += 32) {
         EvdrFwdParams p{};
         p.Q = Qp;
@@ -66,6 +68,8 @@ int run_fwd(const uint16_t* Qp, int64_t q_stride, int64_t q_plane_stride, const 
         p.P = Pp;
         p.p_stride = p_stride;
         p.p_plane_stride = p_plane_stride;
+        p.q_amax = q_amax;
+        p.p_amax = p_amax;
         p.qmask = qmask;
         p.tilemask = tilemask;
         p.pageflags = pageflags;
@@ -103,11 +107,11 @@ int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, uint32_t* tile
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "pack_pmask launch");
 }
 
-int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, void* hip_stream) {
+int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, void* hip_stream) {
     if (rows < 0) return fail(EVDR_ERR_ARG, "evdr_split_f32: negative rows");
-    if (rows == 0) return EVDR_OK;
-    if (!x || !planes) return fail(EVDR_ERR_ARG, "evdr_split_f32: null pointer");
-    hipError_t e = evdr_launch_split_f32(x, rows, planes, (hipStream_t)hip_stream);
+    if (!amax_bits) return fail(EVDR_ERR_ARG, "evdr_split_f32: null amax_bits");
+    if (rows > 0 && (!x || !planes)) return fail(EVDR_ERR_ARG, "evdr_split_f32: null pointer");
+    hipError_t e = evdr_launch_split_f32(x, rows, planes, amax_bits, (hipStream_t)hip_stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "split_f32 launch");
 }
 
@@ -139,30 +143,33 @@ int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const ui
     if (e != hipSuccess) return hip_fail(e, "pack_pmask launch");
     if (dtype == EVDR_BF16) {
         return run_fwd((const uint16_t*)Q, q_stride, 0, (const uint16_t*)P, p_stride, 0, qmask, tilemask, pageflags, out,
-                       np, argmax_or_null, nq, lq, np, lp, 1, stream);
+                       np, argmax_or_null, nq, lq, np, lp, 1, nullptr, nullptr, stream);
     }
     if (q_stride != lq * EVDR_D || p_stride != lp * EVDR_D)
         return fail(EVDR_ERR_ARG, "fp32 inputs must be dense (make them contiguous before the call)");
     uint16_t* qpl = (uint16_t*)(ws + w.qplanes_off);
     uint16_t* ppl = (uint16_t*)(ws + w.pplanes_off);
-    if ((e = evdr_launch_split_f32((const float*)Q, nq * lq, qpl, stream)) != hipSuccess) return hip_fail(e, "split Q");
-    if ((e = evdr_launch_split_f32((const float*)P, np * lp, ppl, stream)) != hipSuccess) return hip_fail(e, "split P");
+    uint32_t* amax = (uint32_t*)(ws + w.amax_off);
+    if ((e = evdr_launch_split_f32((const float*)Q, nq * lq, qpl, amax, stream)) != hipSuccess) return hip_fail(e, "split Q");
+    if ((e = evdr_launch_split_f32((const float*)P, np * lp, ppl, amax + 1, stream)) != hipSuccess) return hip_fail(e, "split P");
     return run_fwd(qpl, lq * EVDR_D, nq * lq * EVDR_D, ppl, lp * EVDR_D, np * lp * EVDR_D, qmask, tilemask, pageflags, out,
-                   np, argmax_or_null, nq, lq, np, lp, 3, stream);
+                   np, argmax_or_null, nq, lq, np, lp, 2, amax, amax + 1, stream);
 }
 
 int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes, const uint8_t* qmask,
                              const uint32_t* tilemask, const uint32_t* pageflags, float* out, int64_t out_stride,
                              uint16_t* argmax_or_null, int64_t nq, int64_t lq, int64_t np, int64_t lp, int nplanes,
-                             int64_t p_stride, int64_t p_plane_stride, void* hip_stream) {
+                             int64_t p_stride, int64_t p_plane_stride, const uint32_t* q_amax_or_null,
+                             const uint32_t* p_amax_or_null, void* hip_stream) {
     if (int rc = check_common(nq, lq, np, lp)) return rc;
-    if (nplanes != 1 && nplanes != 3) return fail(EVDR_ERR_ARG, "nplanes must be 1 or 3");
+    if (nplanes != 1 && nplanes != 2) return fail(EVDR_ERR_ARG, "nplanes must be 1 (bf16) or 2 (fp16 hi/lo)");
     if (nq == 0 || np == 0) return EVDR_OK;
     if (lq == 0 || lp == 0) return fail(EVDR_ERR_SHAPE, "zero-length token axis");
     if (!Qplanes || !Pplanes || !tilemask || !pageflags || !out) return fail(EVDR_ERR_ARG, "evdr_maxsim_fwd_prepared: null pointer");
     if (out_stride < np || p_stride < lp * EVDR_D) return fail(EVDR_ERR_ARG, "stride smaller than the row it spans");
     return run_fwd(Qplanes, lq * EVDR_D, nq * lq * EVDR_D, Pplanes, p_stride, p_plane_stride, qmask, tilemask, pageflags, out,
-                   out_stride, argmax_or_null, nq, lq, np, lp, nplanes, (hipStream_t)hip_stream);
+                   out_stride, argmax_or_null, nq, lq, np, lp, nplanes, nplanes == 2 ? q_amax_or_null : nullptr,
+                   nplanes == 2 ? p_amax_or_null : nullptr, (hipStream_t)hip_stream);
 }
 
 int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
@@ -259,14 +266,15 @@ size_t evdr_maxsim_topk_workspace(int64_t nq, int64_t np) {
 
 int evdr_maxsim_topk(const uint16_t* Qplanes, const uint16_t* Pplanes, const uint8_t* qmask, const uint32_t* tilemask,
                      const uint32_t* pageflags, int64_t nq, int64_t lq, int64_t np, int64_t lp, int nplanes,
-                     int64_t p_stride, int64_t p_plane_stride, int32_t idx_base, int k, float* top_scores,
+                     int64_t p_stride, int64_t p_plane_stride, const uint32_t* q_amax_or_null,
+                     const uint32_t* p_amax_or_null, int32_t idx_base, int k, float* top_scores,
                      int32_t* top_idx, void* workspace, size_t workspace_bytes, void* hip_stream) {
     if (!workspace || workspace_bytes < evdr_maxsim_topk_workspace(nq, np))
         return fail(EVDR_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu",
                     evdr_maxsim_topk_workspace(nq, np), workspace_bytes);
     float* scores = (float*)workspace;
     int rc = evdr_maxsim_fwd_prepared(Qplanes, Pplanes, qmask, tilemask, pageflags, scores, np, nullptr, nq, lq, np, lp,
-                                      nplanes, p_stride, p_plane_stride, hip_stream);
+                                      nplanes, p_stride, p_plane_stride, q_amax_or_null, p_amax_or_null, hip_stream);
     if (rc != EVDR_OK) return rc;
     return evdr_topk(scores, nullptr, nq, np, np, idx_base, k, top_scores, top_idx, hip_stream);
 }

@@ -9,11 +9,19 @@
 #define EVDR_VERSION_NUM 100   /* 0.1.0 */
 
 #define EVDR_D 128              /* embedding width the kernels are specialised for */
-#define EVDR_TILE_PATCHES 32    /* patches per MFMA tile (mfma_f32_32x32x16_bf16 rows) */
+#define EVDR_TILE_PATCHES 32    /* patches per LDS tile (two 16-row MFMA halves) */
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// fp32 -> fp16 hi/lo planes: the tensor is scaled by 2^k so that its absmax lands in [2^14, 2^15) (top of the fp16 range:
+// the lo plane of every element that matters stays a NORMAL fp16 number).  k from the absmax's exponent field; tensors
+// whose absmax is 0, denormal, inf or NaN are left unscaled.
+__host__ __device__ static inline int evdr_h2_shift(uint32_t amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xFFu);
+    return (e == 0 || e == 255) ? 0 : 141 - e;
+}
 
 // ---- forward --------------------------------------------------------------------------------
 struct EvdrFwdParams {
@@ -23,6 +31,8 @@ struct EvdrFwdParams {
     const uint16_t* P;          // bf16 planes; page-major (np, lp, 128) per plane
     int64_t p_stride;           // elements between pages
     int64_t p_plane_stride;     // elements between P planes
+    const uint32_t* q_amax;     // fp16 hi/lo planes (nplanes = 2): absmax bits of the fp32 tensor they were split from
+    const uint32_t* p_amax;     //   (evdr_h2_shift gives the power-of-two the planes were scaled by); null = unscaled
     const uint8_t* qmask;       // (nq, lq) or null
     const uint32_t* tilemask;   // (np, ntiles)
     const uint32_t* pageflags;  // (np)
@@ -79,10 +89,11 @@ static inline hipError_t evdr_ensure_dyn_lds(const void* kern, int bytes, uint64
 
 // launches (defined in the .hip files; all enqueue on `stream` and return the launch status)
 hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& p, int nplanes, bool want_argmax, hipStream_t stream);
-hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int geom, hipStream_t stream);
+hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes, bool want_argmax, int geom,
+                                    hipStream_t stream);
 hipError_t evdr_launch_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, uint32_t* tilemask,
                                   uint32_t* pageflags, hipStream_t stream);
-hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes, hipStream_t stream);
+hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, hipStream_t stream);
 hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                   const uint16_t* argmax, float* dP, int64_t nq, int64_t lq, int64_t np,
                                   int64_t lp, hipStream_t stream);

@@ -1,4 +1,4 @@
-// MaxSim forward on the 16x16x32 bf16 MFMA shape (bf16 retrieval hot path: NPL = 1, no argmax).
+// MaxSim forward on the 16x16x32 MFMA shape: bf16 inputs (retrieval hot path) and fp32 inputs as fp16 hi/lo planes.
 //
 // Same structure as maxsim_fwd.hip (queries resident as the MFMA B operand, token on the lane, LDS-DMA ring,
 // XOR-swizzled conflict-free A reads, XCD-aware block map, fast path for all-valid tiles).  Why a second
@@ -217,13 +217,21 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
 // ---- page-aligned stages, straight-line fast stage ---------------------------------------------------------------
 // Ring stages are aligned to pages: a page of T tiles is ceil(T/ST) stages, the last one short -- or, when T = k*ST + 1,
 // k stages whose last one carries the extra tile in a ring slot of ST + 1 tiles (a 1030-patch page = 3 stages of 8 full
-// tiles + 1 stage of 8 full tiles and the 6-patch tail tile).  A stage whose 4 tiles are all valid and belong
-// to one page -- 32 of the 33 tiles of such a page -- runs as ONE basic block: 8 half-tile steps x 8 chains x 4 MFMAs
-// per wave with no branch, no scalar load and no wait other than the LDS counters in between, so the compiler overlaps
-// every v_max3 epilogue and every ds_read with MFMAs of the following chains (the per-tile schedule lost ~28 % of the
+// tiles + 1 stage of 8 full tiles and the 6-patch tail tile).  A stage whose ST tiles are all valid and belong
+// to one page -- 32 of the 33 tiles of such a page -- runs as ONE basic block: 2*ST half-tile steps x 2*QW chains per
+// wave with no branch, no scalar load and no wait other than the LDS counters in between, so the compiler overlaps
+// every epilogue and every ds_read with MFMAs of the following chains (the per-tile schedule lost ~28 % of the
 // matrix pipe to the gaps between tiles).  Other stages (tail tile, masked pages) take the per-tile path.
 // Tile masks of prefix-style pages (flag bit2) are derived from the valid length; mask words are only read for pages
-// with holes.  The short stage re-fetches its last tile into the unused ring rows (+9 % L2->LDS traffic, no HBM).
+// with holes.
+//
+// NPL = 1: bf16 inputs, one product per k-step.
+// NPL = 2: fp32 inputs as two fp16 planes hi/lo of x * 2^k (k per tensor from its absmax, evdr_h2_shift): three plane
+//          products lo*hi + hi*lo + hi*hi per k-step reproduce the fp32 dot product to ~2^-22 relative, below the
+//          rounding noise of an fp32 accumulation; scores are rescaled by 2^-(kq + kp) at the page end, where the -1e4 of
+//          masked patches (evaluator/retrieval.py:185,198) joins the max in real units.
+// ARGMAX: also writes, per (query, page, token), the first patch index attaining the max (what torch.max returns and
+//          autograd routes the gradient to).
 // DIAG instantiation: s_memtime stamps around the segments of a wave's life, summed per wave and written to p.dbg
 // ([block][wave][8] cycles: total, prologue, barrier wait, top-of-stage refill, fast block, generic stage, page
 // finish, stages).  Its fences forbid overlaps the real kernel has: read SHARES, never its run time.
@@ -235,13 +243,51 @@ __device__ __forceinline__ unsigned long long stamp() {
     return t;
 }
 
-template <int QW, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <int NPL> struct FragOf { using type = bf16x8; };
+template <> struct FragOf<2> { using type = f16x8; };
+__device__ __forceinline__ f32x4v mfma16(const bf16x8& a, const bf16x8& b, const f32x4v& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4v mfma16(const f16x8& a, const f16x8& b, const f32x4v& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// (value, index) reduction over the four lane groups {l, l^16, l^32, l^48}: larger value wins, equal values -> lower index
+__device__ __forceinline__ void xgroup_argmax(float& v, int& idx) {
+    {
+        float a = v, b = v, ia = __builtin_bit_cast(float, idx), ib = ia;
+        swap16(a, b);
+        swap16(ia, ib);
+        const int xa = __builtin_bit_cast(int, ia), xb = __builtin_bit_cast(int, ib);
+        const bool tb = (b > a) || (b == a && xb < xa);
+        v = tb ? b : a;
+        idx = tb ? xb : xa;
+    }
+    {
+        float a = v, b = v, ia = __builtin_bit_cast(float, idx), ib = ia;
+        swap32(a, b);
+        swap32(ia, ib);
+        const int xa = __builtin_bit_cast(int, ia), xb = __builtin_bit_cast(int, ib);
+        const bool tb = (b > a) || (b == a && xb < xa);
+        v = tb ? b : a;
+        idx = tb ? xb : xa;
+    }
+}
+
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
 __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
+    using frag = typename FragOf<NPL>::type;
     constexpr int WAVES = 8;
+    constexpr int TILE_B = NPL * TILE_BYTES;              // planes of one tile are adjacent 8-KiB images
     constexpr int SLOT_TILES = ST + 1;                    // a ring slot holds one tile more than a stage's ST ...
-    constexpr int STAGE_BYTES = SLOT_TILES * TILE_BYTES;
-    constexpr int G = ST * 8 / WAVES;
-    static_assert(G * WAVES == ST * 8 && WAVES == 8, "one LDS-DMA piece of the extra tile per wave");
+    constexpr int STAGE_BYTES = SLOT_TILES * TILE_B;
+    constexpr int G = ST * NPL;                           // LDS-DMA pieces per wave per stage (8 pieces per tile and plane)
+    // plane products (A = page plane, B = query plane), smaller magnitude first
+    constexpr int NPROD = (NPL == 1) ? 1 : 3;
+    constexpr int PA[3] = {NPL - 1, 0, 0};
+    constexpr int PB[3] = {0, NPL - 1, 0};
+    static_assert(NPL == 1 || NPL == 2, "one bf16 plane or fp16 hi/lo planes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -262,7 +308,7 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
 
     const int q0 = (qg * WAVES + wave) * QW;
     const bool active = q0 < p.nq;
-    bf16x8 bq[QW][2][4];
+    frag bq[QW][NPL][2][4];
     float qwt[QW][2];
 #pragma unroll
     for (int j = 0; j < QW; ++j) {
@@ -273,20 +319,29 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
             const bool ok = (q < p.nq) && (tok < p.lq);
             const int64_t row = (int64_t)q * p.q_stride + (int64_t)(p.tok0 + tok) * EVDR_D + g * 8;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok) v = *reinterpret_cast<const bf16x8*>(p.Q + row + s * 32);
-                bq[j][t][s] = v;
-            }
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    frag v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ok) v = *reinterpret_cast<const frag*>(p.Q + pl * p.q_plane_stride + row + s * 32);
+                    bq[j][pl][t][s] = v;
+                }
             float w = 0.f;
             if (ok) w = (p.qmask == nullptr || p.qmask[(int64_t)q * p.lq_total + p.tok0 + tok] != 0) ? 1.f : 0.f;
             qwt[j][t] = w;
         }
     }
+    // fp16 planes carry x * 2^k: scores come back to real units with one exact power-of-two factor
+    float inv = 1.f;
+    if constexpr (NPL == 2) {
+        const int kq = p.q_amax ? evdr_h2_shift(*p.q_amax) : 0;
+        const int kp = p.p_amax ? evdr_h2_shift(*p.p_amax) : 0;
+        inv = __builtin_ldexpf(1.f, -(kq + kp));
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const uint32_t smem_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
-    // stage S = page (S / spp), tiles 4 (S % spp) .. +3 of that page (rows beyond the page are clamped: masked anyway)
+    // stage S = page (S / spp), tiles ST (S % spp) .. of that page (rows beyond the page are clamped: masked anyway)
     // Per-lane byte offset of this lane's 16 B inside a 1-KiB piece: LDS row (4 piece + lane/16) of the tile receives source
     // chunk (lane%16) ^ (row & 15) of patch row (row0 + lane/16).  swz[q] = the swizzled chunk offset for piece & 3 == q.
     // The DMA's lane offset is zero-extended, so rows past the page end (masked anyway) are clamped by clamping the
@@ -301,75 +356,121 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
         const int pgi = S / spp;
         const int t0 = (S - pgi * spp) * ST;
         const int pc = wave * G + i;
-        const int tis = pc >> 3, piece = pc & 7;
+        const int tis = pc / (8 * NPL);
+        const int rem = pc - tis * (8 * NPL);
+        const int pl = rem >> 3, piece = rem & 7;
         // with a 2-slot ring every wait is vmcnt(0), so tiles beyond the page need not be fetched at all
         if (!KNOWN_FULL && NSTAGE == 2 && t0 + tis >= p.ntiles) return;
         const int row0 = (t0 + tis) * EVDR_TILE_PATCHES + piece * 4;                 // first patch row of the piece (uniform)
         const int rbase = min(row0, p.lp - 1);
-        const uint16_t* sb = p.P + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
+        const uint16_t* sb = p.P + (int64_t)pl * p.p_plane_stride + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
         uint32_t voff = swz[piece & 3] + lgoff;
         if (!KNOWN_FULL && row0 + 3 >= p.lp)                                         // uniform: only a page's tail tile
             voff = swz[piece & 3] + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
-        lds_dma_16B_sbase(sb, voff, __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + tis * TILE_BYTES + piece * 1024));
+        lds_dma_16B_sbase(sb, voff,
+                          __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + tis * TILE_B + pl * TILE_BYTES + piece * 1024));
     };
-    // the extra (ST-th) tile of an extended last stage: piece `wave` of that tile, one per wave, always clamped
+    // the extra (ST-th) tile of an extended last stage: piece `wave` of each plane of that tile, always clamped
     auto issue_extra = [&](int S, int slot) {
         const int pgi = S / spp;
         const int k = S - pgi * spp;
         if (!(ext && k == spp - 1)) return;
         const int row0 = (k * ST + ST) * EVDR_TILE_PATCHES + wave * 4;
         const int rbase = min(row0, p.lp - 1);
-        const uint16_t* sb = p.P + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
         const uint32_t voff = swz[wave & 3] + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
-        lds_dma_16B_sbase(sb, voff, __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + ST * TILE_BYTES + wave * 1024));
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            const uint16_t* sb = p.P + (int64_t)pl * p.p_plane_stride + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
+            lds_dma_16B_sbase(sb, voff,
+                              __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + ST * TILE_B + pl * TILE_BYTES + wave * 1024));
+        }
     };
     auto issue_stage = [&](int S, int slot) {
 #pragma unroll
         for (int i = 0; i < G; ++i) issue_piece(S, slot, i, std::false_type{});
         issue_extra(S, slot);
     };
-    constexpr bool SPREAD = (NSTAGE == 2) && (G == ST);      // one piece per tile of the straight-line block
+    // in-block refill: NPL pieces per tile of the straight-line block (not for QW = 2 on fp16 planes: the piece addressing
+    // pushes that instance over the register file, and a scratch reload inside the block would wait on the DMA queue)
+    constexpr bool SPREAD = (NSTAGE == 2) && !(NPL == 2 && QW == 2);
 
     typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
     cptr_t tilemask_c = (cptr_t)(uintptr_t)p.tilemask;
     cptr_t pageflags_c = (cptr_t)(uintptr_t)p.pageflags;
 
     float run[QW][2];
+    int ridx[QW][2];
     const int gx = g ^ c;
     const char* a_lane = smem + c * (EVDR_D * 2);
-    auto load_half = [&](bf16x8 (&a)[4], const char* sbase, int tis, int u) {
-        const char* tb = sbase + tis * TILE_BYTES + u * (16 * EVDR_D * 2);
+    auto load_half = [&](frag (&a)[NPL][4], const char* sbase, int tis, int u) {
+        const char* tb = sbase + tis * TILE_B + u * (16 * EVDR_D * 2);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) a[s4] = *reinterpret_cast<const bf16x8*>(tb + (((4 * s4) ^ gx) << 4));
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) a[pl][s4] = *reinterpret_cast<const frag*>(tb + pl * TILE_BYTES + (((4 * s4) ^ gx) << 4));
     };
-    auto chains_full = [&](const bf16x8 (&a)[4]) {           // all 16 patches of the half valid
+    auto chain = [&](const frag (&a)[NPL][4], int j, int t) {
+        f32x4v acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int pr = 0; pr < NPROD; ++pr)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = mfma16(a[PA[pr]][s4], bq[j][PB[pr]][t][s4], acc);
+        return acc;
+    };
+    // fold one chain's accumulator (patches pb .. pb + 3 of this lane, all valid) into the running max / argmax
+    auto fold = [&](const f32x4v& acc, int j, int t, int pb) {
+        if constexpr (!ARGMAX) {
+            float m = run[j][t];
+            m = __builtin_fmaxf(__builtin_fmaxf(m, acc[0]), acc[1]);
+            m = __builtin_fmaxf(__builtin_fmaxf(m, acc[2]), acc[3]);
+            run[j][t] = m;
+        } else {
+            float best = run[j][t];
+            int bi = ridx[j][t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                                  // increasing patch order: the first max wins
+                const bool take = acc[i] > best;
+                best = take ? acc[i] : best;
+                bi = take ? pb + i : bi;
+            }
+            run[j][t] = best;
+            ridx[j][t] = bi;
+        }
+    };
+    // pbase: first patch index of the 16-patch half (uniform); the lane's accumulator i is patch pbase + 4g + i
+    auto chains_full = [&](const frag (&a)[NPL][4], int pbase) {           // all 16 patches of the half valid
+        const int pb = pbase + 4 * g;
 #pragma unroll
         for (int j = 0; j < QW; ++j)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4v acc = {0, 0, 0, 0};
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s4], bq[j][t][s4], acc, 0, 0, 0);
-                float m = run[j][t];
-                m = __builtin_fmaxf(__builtin_fmaxf(m, acc[0]), acc[1]);
-                m = __builtin_fmaxf(__builtin_fmaxf(m, acc[2]), acc[3]);
-                run[j][t] = m;
-            }
+            for (int t = 0; t < 2; ++t) fold(chain(a, j, t), j, t, pb);
     };
-    auto chains_masked = [&](const bf16x8 (&a)[4], uint32_t bits) {
+    auto chains_masked = [&](const frag (&a)[NPL][4], uint32_t bits, int pbase) {
+        const int pb = pbase + 4 * g;
         uint32_t mybits = bits >> (4 * g);
         asm volatile("" : "+v"(mybits));
 #pragma unroll
         for (int j = 0; j < QW; ++j)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                f32x4v acc = {0, 0, 0, 0};
+                const f32x4v acc = chain(a, j, t);
+                if constexpr (!ARGMAX) {
+                    float m = run[j][t];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s4], bq[j][t][s4], acc, 0, 0, 0);
-                float m = run[j][t];
+                    for (int i = 0; i < 4; ++i) m = __builtin_fmaxf(m, ((mybits >> i) & 1u) ? acc[i] : neg_inf());
+                    run[j][t] = m;
+                } else {
+                    float best = run[j][t];
+                    int bi = ridx[j][t];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) m = __builtin_fmaxf(m, ((mybits >> i) & 1u) ? acc[i] : neg_inf());
-                run[j][t] = m;
+                    for (int i = 0; i < 4; ++i) {
+                        const bool take = ((mybits >> i) & 1u) && (acc[i] > best);
+                        best = take ? acc[i] : best;
+                        bi = take ? pb + i : bi;
+                    }
+                    run[j][t] = best;
+                    ridx[j][t] = bi;
+                }
             }
     };
 
@@ -383,7 +484,12 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
         const uint32_t pflags = pageflags_c[page];
         const int vlen = (pflags & 4u) ? ((pflags & 2u) ? (int)(pflags >> 16) : p.lp) : -1;    // -1: page with holes
 #pragma unroll
-        for (int j = 0; j < QW; ++j) run[j][0] = run[j][1] = (pflags & 2u) ? -1e4f : neg_inf();
+        for (int j = 0; j < QW; ++j) {
+            // NPL = 1: a masked patch inside [0, lp) puts -1e4 into the max right away; NPL = 2 works in scaled units and
+            // lets the -1e4 join at the page end
+            run[j][0] = run[j][1] = (NPL == 1 && (pflags & 2u)) ? -1e4f : neg_inf();
+            ridx[j][0] = ridx[j][1] = (NPL == 1) ? (int)(pflags >> 16) : 0;
+        }
 
         for (int k = 0; k < spp; ++k, ++S) {
             if constexpr (DIAG) d_a = stamp();
@@ -395,7 +501,7 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
             const int t0 = k * ST;
             const bool fast = active && (vlen - t0 * EVDR_TILE_PATCHES >= ST * EVDR_TILE_PATCHES);
             // In-block refill: when this stage runs the straight-line block AND the next stage is a full one (all ST tiles
-            // exist and lie inside the page rows), its LDS-DMA pieces are issued one per tile INSIDE the block, where their
+            // exist and lie inside the page rows), its LDS-DMA pieces are issued NPL per tile INSIDE the block, where their
             // scalar/address work hides under MFMAs; otherwise the refill is issued here, right after the barrier.
             const bool next_full = refill && (k + 1 < spp ? (k + 2) * ST * EVDR_TILE_PATCHES <= p.lp
                                                           : ST * EVDR_TILE_PATCHES <= p.lp);
@@ -418,9 +524,10 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                 for (int u = 0; u < 2; ++u) {
                     const uint32_t bits = (tm >> (16 * u)) & 0xFFFFu;
                     if (bits == 0u) continue;
-                    bf16x8 a[4];
+                    frag a[NPL][4];
                     load_half(a, sbase, tis, u);
-                    if (bits == 0xFFFFu) chains_full(a); else chains_masked(a, bits);
+                    const int pbase = tip * EVDR_TILE_PATCHES + 16 * u;
+                    if (bits == 0xFFFFu) chains_full(a, pbase); else chains_masked(a, bits, pbase);
                 }
             };
             if (active) {
@@ -429,35 +536,95 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                     auto fast_block = [&](auto spread_tag, auto young_tag) {
                         constexpr bool SP = decltype(spread_tag)::value;
                         constexpr bool YOUNG = decltype(young_tag)::value;   // second-dispatched half of the workgroup
-                        bf16x8 alo[4], ahi[4];
-                        load_half(alo, sbase, 0, 0);
-                        load_half(ahi, sbase, 0, 1);
-#pragma unroll
-                        for (int tis = 0; tis < ST; ++tis) {
-                            // self-balancing priority: 3,2,1,0 over the quarters of the block.  The two waves of a SIMD run this
-                            // same block; the one the arbiter favours reaches the lower-priority quarters first and yields, so
-                            // both arrive at the stage barrier together instead of one idling while the other finishes alone.
+                        // self-balancing priority: 3,2,1,0 over the quarters of the block.  The two waves of a SIMD run this
+                        // same block; the one the arbiter favours reaches the lower-priority quarters first and yields, so
+                        // both arrive at the stage barrier together instead of one idling while the other finishes alone.
+                        // Priority falls with progress (half-tile step h of 2 ST): second-dispatched half of the workgroup
+                        // 3,3,2,2,1,1,0,0 (per tile, ST = 8); first half, which wins equal-priority arbitration by age, an
+                        // eighth of the block earlier: 3,2,2,1,1,0,0,0
+                        auto prio_at = [](int h) {
+                            const int off = YOUNG ? 0 : (ST >= 4 ? ST / 4 : 1);
+                            const int q = 4 * (h + off) / (2 * ST);
+                            return 3 - (q > 3 ? 3 : q);
+                        };
+                        auto set_prio = [&](int h) {
                             if constexpr (BAL) {
-                                // priority falls with progress (tile index u): second-dispatched half 3,3,2,2,1,1,0,0;
-                                // first half, which wins equal-priority arbitration by age, half a step lower: 3,2,2,1,1,0,0,0
-                                static_assert(ST == 8, "priority schedule is written for 8-tile stages");
-                                if constexpr (YOUNG) {
-                                    if (tis == 0) __builtin_amdgcn_s_setprio(3);
-                                    else if (tis == 2) __builtin_amdgcn_s_setprio(2);
-                                    else if (tis == 4) __builtin_amdgcn_s_setprio(1);
-                                    else if (tis == 6) __builtin_amdgcn_s_setprio(0);
-                                } else {
-                                    if (tis == 0) __builtin_amdgcn_s_setprio(3);
-                                    else if (tis == 1) __builtin_amdgcn_s_setprio(2);
-                                    else if (tis == 3) __builtin_amdgcn_s_setprio(1);
-                                    else if (tis == 5) __builtin_amdgcn_s_setprio(0);
+                                const int pr = prio_at(h);
+                                if (h == 0 || pr != prio_at(h - 1)) {
+                                    if (pr == 3) __builtin_amdgcn_s_setprio(3);
+                                    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+                                    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+                                    else __builtin_amdgcn_s_setprio(0);
                                 }
                             }
-                            chains_full(alo);
-                            if (tis + 1 < ST) load_half(alo, sbase, tis + 1, 0);
-                            if constexpr (SP) issue_piece(S + 1, nslot, tis, std::true_type{});
-                            chains_full(ahi);
-                            if (tis + 1 < ST) load_half(ahi, sbase, tis + 1, 1);
+                        };
+                        if constexpr (NPL == 1) {
+                            frag alo[NPL][4], ahi[NPL][4];
+                            load_half(alo, sbase, 0, 0);
+                            load_half(ahi, sbase, 0, 1);
+#pragma unroll
+                            for (int tis = 0; tis < ST; ++tis) {
+                                const int pbase = (t0 + tis) * EVDR_TILE_PATCHES;
+                                set_prio(2 * tis);
+                                chains_full(alo, pbase);
+                                if (tis + 1 < ST) load_half(alo, sbase, tis + 1, 0);
+                                if constexpr (SP) issue_piece(S + 1, nslot, tis, std::true_type{});
+                                set_prio(2 * tis + 1);
+                                chains_full(ahi, pbase + 16);
+                                if (tis + 1 < ST) load_half(ahi, sbase, tis + 1, 1);
+                            }
+                        } else {
+                            // fp16 hi/lo planes: per 16-patch half, phase 1 = page-lo x query-hi on all 2 QW chains, phase 2 =
+                            // page-hi x query-lo, then page-hi x query-hi.  Only ONE plane's fragments of the current half and
+                            // the prefetched plane of the next are live (32 VGPRs instead of 64 for both planes of both halves),
+                            // which is what lets QW = 2 (128 VGPRs of query fragments) fit; accumulation order per chain is
+                            // the same as chain()'s.
+                            auto load_plane = [&](frag (&a)[4], int h, int pl) {
+                                const char* tb = sbase + (h >> 1) * TILE_B + (h & 1) * (16 * EVDR_D * 2) + pl * TILE_BYTES;
+#pragma unroll
+                                for (int s4 = 0; s4 < 4; ++s4) a[s4] = *reinterpret_cast<const frag*>(tb + (((4 * s4) ^ gx) << 4));
+                            };
+                            frag al[4], ah[4];
+                            load_plane(al, 0, 1);
+                            load_plane(ah, 0, 0);
+#pragma unroll
+                            for (int h = 0; h < 2 * ST; ++h) {
+                                set_prio(h);
+                                f32x4v acc[QW][2];
+#pragma unroll
+                                for (int j = 0; j < QW; ++j) acc[j][0] = acc[j][1] = f32x4v{0, 0, 0, 0};
+#pragma unroll
+                                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                                    for (int j = 0; j < QW; ++j)
+#pragma unroll
+                                        for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(al[s4], bq[j][0][t][s4], acc[j][t]);
+                                if (h + 1 < 2 * ST) load_plane(al, h + 1, 1);
+                                if constexpr (SP) {
+                                    if ((h & 1) == 0) {
+#pragma unroll
+                                        for (int pl = 0; pl < NPL; ++pl) issue_piece(S + 1, nslot, (h >> 1) * NPL + pl, std::true_type{});
+                                    }
+                                }
+#pragma unroll
+                                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                                    for (int j = 0; j < QW; ++j)
+#pragma unroll
+                                        for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][1][t][s4], acc[j][t]);
+#pragma unroll
+                                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                                    for (int j = 0; j < QW; ++j)
+#pragma unroll
+                                        for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][0][t][s4], acc[j][t]);
+                                if (h + 1 < 2 * ST) load_plane(ah, h + 1, 0);
+                                const int pb = (t0 + (h >> 1)) * EVDR_TILE_PATCHES + 16 * (h & 1) + 4 * g;
+#pragma unroll
+                                for (int j = 0; j < QW; ++j)
+#pragma unroll
+                                    for (int t = 0; t < 2; ++t) fold(acc[j][t], j, t, pb);
+                            }
                         }
                     };
                     // one straight-line instance per (refill placement, workgroup half): no run-time branch inside the block
@@ -466,7 +633,7 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                     } else {
                         if (spread) fast_block(std::true_type{}, std::false_type{}); else fast_block(std::false_type{}, std::false_type{});
                     }
-                    if (spread) issue_extra(S + 1, nslot);               // the next stage's tail-tile piece, after the block
+                    if (spread) issue_extra(S + 1, nslot);               // the next stage's tail-tile pieces, after the block
                     if constexpr (DIAG) { const unsigned long long t = stamp(); d_fast += t - d_a; d_a = t; }
                     if (nt > ST) generic_tile(ST);                       // tail tile riding in this (last) stage
                 } else {
@@ -485,7 +652,24 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                 float cs = 0.f;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    cs += xgroup_max(run[j][t]) * has * qwt[j][t];
+                    float v = run[j][t];
+                    int bi = ridx[j][t];
+                    if constexpr (ARGMAX) xgroup_argmax(v, bi); else v = xgroup_max(v);
+                    if constexpr (NPL == 2) {
+                        v *= inv;
+                        if (pflags & 2u) {                                 // the masked patches' -1e4 joins the max here
+                            const int fm = (int)(pflags >> 16);
+                            const bool take = (-1e4f > v) || (-1e4f == v && fm < bi);
+                            v = take ? -1e4f : v;
+                            bi = take ? fm : bi;
+                        }
+                    }
+                    if constexpr (ARGMAX) {
+                        const int tok = 16 * t + c;
+                        if (g == 0 && tok < p.lq && q0 + j < p.nq)
+                            p.argmax[((int64_t)(q0 + j) * p.np + page) * p.lq_total + p.tok0 + tok] = (uint16_t)bi;
+                    }
+                    cs += v * has * qwt[j][t];
                 }
                 cs = row16_sum(cs);
                 if (lane == 0 && q0 + j < p.nq) {
@@ -506,11 +690,11 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
     }
 }
 
-template <int QW, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
 hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
-    constexpr int LDS = NSTAGE * (ST + 1) * TILE_BYTES;
-    auto kern = maxsim_fwd16s_kernel<QW, ST, NSTAGE, DIAG, BAL, OCC>;
+    constexpr int LDS = NSTAGE * (ST + 1) * NPL * TILE_BYTES;
+    auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC>;
     static uint64_t attr_devs = 0;
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, 8 * QW);
@@ -532,25 +716,31 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
 
 }  // namespace
 
-// geom 0 (default): page-aligned 8-tile stages with the self-balancing priority schedule (maxsim_fwd16s_kernel) for pages
-// of >= 8 tiles, the flat per-tile ring (maxsim_fwd16_kernel) for shorter pages; geom 1 forces the flat kernel, geom 2 the
-// staged kernel without the priority schedule (A/B experiments); 50/51 are the stamped diagnostic builds.
-hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int geom, hipStream_t stream) {
+// NPL = 1 without argmax (retrieval / eval): geom 0 (default) = page-aligned 8-tile stages with the self-balancing priority
+// schedule (maxsim_fwd16s_kernel) for pages of >= 8 tiles, the flat per-tile ring (maxsim_fwd16_kernel) for shorter
+// pages; geom 1 forces the flat kernel, geom 2 the staged kernel without the priority schedule, 3 a deeper flat ring,
+// 4 two workgroups per CU (A/B experiments); 50/51 are the stamped diagnostic builds.
+// Argmax and fp16 hi/lo planes (nplanes = 2): the staged kernel for every page length.
+hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes, bool want_argmax, int geom, hipStream_t stream) {
     const int ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
+    if (nplanes == 2) {                                  // 4-tile stages of 16-KiB tiles: 2 x 5 x 16 KiB = all 160 KiB of LDS
+        if (want_argmax) return qw == 2 ? launch16s<2, 2, true, 4, 2, false, true>(p, stream) : launch16s<1, 2, true, 4, 2, false, true>(p, stream);
+        return qw == 2 ? launch16s<2, 2, false, 4, 2, false, true>(p, stream) : launch16s<1, 2, false, 4, 2, false, true>(p, stream);
+    }
+    if (want_argmax) return qw == 2 ? launch16s<2, 1, true, 8, 2, false, true>(p, stream) : launch16s<1, 1, true, 8, 2, false, true>(p, stream);
     if ((geom == 50 || geom == 51) && ntiles >= 8 && qw == 4) {   // diagnostic builds with in-kernel stamps (scratch/diag_stamps.py)
         EvdrFwdParams pd = p;
         const char* e = getenv("EVDR_DBG_PTR");
         pd.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr;
-        return geom == 50 ? launch16s<4, 8, 2, true, false>(pd, stream) : launch16s<4, 8, 2, true, true>(pd, stream);
+        return geom == 50 ? launch16s<4, 1, false, 8, 2, true, false>(pd, stream) : launch16s<4, 1, false, 8, 2, true, true>(pd, stream);
     }
-    if (geom == 2 && ntiles >= 8 && qw == 4) return launch16s<4, 8, 2, false, false>(p, stream);   // A/B: no priority schedule
-    if (geom != 1 && geom != 3 && !(geom == 4 && qw == 1) && ntiles >= 8) {
-        if (qw == 4) return launch16s<4, 8, 2, false, true>(p, stream);
-        if (qw == 2) return launch16s<2, 8, 2, false, true>(p, stream);
-        return launch16s<1, 8, 2, false, true>(p, stream);
+    if (geom == 2 && ntiles >= 8 && qw == 4) return launch16s<4, 1, false, 8, 2, false, false>(p, stream);   // A/B: no priority schedule
+    if (geom == 4 && ntiles >= 8 && qw == 1) return launch16s<1, 1, false, 4, 2, false, false, 4>(p, stream);  // A/B: 2 WGs per CU
+    if (geom != 1 && geom != 3 && geom != 4 && ntiles >= 8) {
+        if (qw == 4) return launch16s<4, 1, false, 8, 2, false, true>(p, stream);
+        if (qw == 2) return launch16s<2, 1, false, 8, 2, false, true>(p, stream);
+        return launch16s<1, 1, false, 8, 2, false, true>(p, stream);
     }
-    if (geom == 4 && ntiles >= 8 && qw == 1)            // A/B: 4-tile stages, two workgroups per CU (80 KiB of LDS each)
-        return launch16s<1, 4, 2, false, false, 4>(p, stream);
     if (geom == 3) {                                    // A/B: deeper flat ring (3 of 4 stages in flight)
         if (qw == 4) return launch16<4, 8, 4, 4>(p, stream);
         if (qw == 2) return launch16<2, 8, 4, 4>(p, stream);

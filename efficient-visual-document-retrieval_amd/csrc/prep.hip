@@ -1,6 +1,6 @@
 // Corpus preparation kernels: HBM-bound byte work either side of the MaxSim loop.
 //   pack_pmask : (np, lp) byte mask -> 32-patch tile words + per-page flags     (reads lp B / page)
-//   split_f32  : fp32 rows -> bf16 hi/mid/lo planes, x == hi + mid + lo          (reads 512 B, writes 768 B / row)
+//   split_f32  : fp32 rows -> absmax, then fp16 hi/lo planes of x * 2^k          (reads 2 x 512 B, writes 512 B / row)
 // Mask semantics follow evaluator/retrieval.py:179-180,192,198 (mask.bool(), doc_has_token, -1e4 fill).
 #include "evdr_common.h"
 
@@ -46,34 +46,47 @@ __global__ void __launch_bounds__(64) pack_pmask_kernel(const uint8_t* __restric
     }
 }
 
-__device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
-    return __builtin_bit_cast(uint16_t, (__bf16)x);   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+// absmax of the tensor as raw bits (|x| as uint32 orders like the float; NaN sorts above inf and poisons the result,
+// as it would poison the reference's scores)
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n4, uint32_t* __restrict__ amax_bits) {
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float f = v[k];      // by value: __builtin_bit_cast on the vector-element lvalue reads element 0 (hipcc 7.2)
+            m = max(m, __builtin_bit_cast(uint32_t, f) & 0x7FFFFFFFu);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    __shared__ uint32_t wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per workgroup: thousands of atomics on one address serialise in L2 (40 us for a 50-MB tensor)
+    if (threadIdx.x == 0) {
+        m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (m != 0u) atomicMax(amax_bits, m);
+    }
 }
-__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 
-// one thread = 8 consecutive floats (two 16-B loads, three 16-B stores)
-__global__ void __launch_bounds__(256) split_f32_kernel(const float* __restrict__ x, int64_t n8,
-                                                        uint16_t* __restrict__ hi, uint16_t* __restrict__ mid,
-                                                        uint16_t* __restrict__ lo) {
+// one thread = 8 consecutive floats (two 16-B loads, two 16-B stores): xs = x * 2^k, hi = fp16(xs), lo = fp16(xs - hi)
+__global__ void __launch_bounds__(256) split_h2_kernel(const float* __restrict__ x, int64_t n8, const uint32_t* __restrict__ amax_bits,
+                                                       _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+    const int k = evdr_h2_shift(*amax_bits);
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + i * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
-        typedef __attribute__((ext_vector_type(8))) uint16_t u16x8;
-        u16x8 a, b, c;
+        f16x8 a, b;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float f = (k < 4) ? v0[k & 3] : v1[k & 3];
-            const uint16_t bh = f32_to_bf16_rne(f);
-            const float r1 = f - bf16_to_f32(bh);          // exact in fp32
-            const uint16_t bm = f32_to_bf16_rne(r1);
-            const float r2 = r1 - bf16_to_f32(bm);         // exact in fp32
-            a[k] = bh;
-            b[k] = bm;
-            c[k] = f32_to_bf16_rne(r2);
+        for (int j = 0; j < 8; ++j) {
+            const float f = __builtin_ldexpf((j < 4) ? v0[j & 3] : v1[j & 3], k);    // exact
+            const _Float16 h = (_Float16)f;                                          // RNE
+            a[j] = h;
+            b[j] = (_Float16)(f - (float)h);                                         // the difference is exact in fp32
         }
-        *reinterpret_cast<u16x8*>(hi + i * 8) = a;
-        *reinterpret_cast<u16x8*>(mid + i * 8) = b;
-        *reinterpret_cast<u16x8*>(lo + i * 8) = c;
+        *reinterpret_cast<f16x8*>(hi + i * 8) = a;
+        *reinterpret_cast<f16x8*>(lo + i * 8) = b;
     }
 }
 
@@ -87,13 +100,17 @@ hipError_t evdr_launch_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, 
     return hipGetLastError();
 }
 
-hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes, hipStream_t stream) {
+hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
     const int64_t n8 = rows * (EVDR_D / 8);
     if (n8 == 0) return hipSuccess;
     int64_t blocks = (n8 + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;     // grid-stride beyond 8 blocks per CU
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream, x, n8 * 2, amax_bits);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     const int64_t plane = rows * EVDR_D;
-    hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n8, planes, planes + plane,
-                       planes + 2 * plane);
+    hipLaunchKernelGGL(split_h2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n8, amax_bits, (_Float16*)planes,
+                       (_Float16*)planes + plane);
     return hipGetLastError();
 }

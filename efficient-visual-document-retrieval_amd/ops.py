@@ -56,18 +56,21 @@ def pack_pmask(pmask: Optional[torch.Tensor], npages: int, lp: int, dev) -> Tupl
     return tilemask, pageflags
 
 
-def split_f32(x: torch.Tensor) -> torch.Tensor:
-    """(..., 128) fp32 -> (3, ..., 128) bf16 planes hi/mid/lo with hi+mid+lo == x to ~2^-24."""
+def split_f32(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(..., 128) fp32 -> ((2, ..., 128) fp16 planes hi/lo of x * 2^k, absmax word): hi + lo == x * 2^k to ~2^-22, with
+    one power of two k per tensor that the kernels derive from the absmax word (int32 tensor of 1 element holding the
+    bits of max|x|; keep it with the planes)."""
     dev = _require_cuda(x)
     if x.shape[-1] != D:
         raise NotImplementedError(f"embedding width {x.shape[-1]} unsupported (kernels are built for {D})")
     lib = L.load()
     xc = x.float().contiguous()
     rows = xc.numel() // D
-    planes = torch.empty((3,) + tuple(xc.shape), dtype=torch.bfloat16, device=dev)
+    planes = torch.empty((2,) + tuple(xc.shape), dtype=torch.float16, device=dev)
+    amax = torch.empty((1,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        L.check(lib.evdr_split_f32(L.ptr(xc), rows, L.ptr(planes), L.current_stream_handle(dev)))
-    return planes
+        L.check(lib.evdr_split_f32(L.ptr(xc), rows, L.ptr(planes), L.ptr(amax), L.current_stream_handle(dev)))
+    return planes, amax
 
 
 def maxsim_forward(Q: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],

@@ -54,9 +54,12 @@ const char* evdr_last_error(void);       /* host string, thread-local, valid unt
 int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp,
                     uint32_t* tilemask, uint32_t* pageflags, void* hip_stream);
 
-/* Split `rows` x 128 fp32 into three bf16 planes hi/mid/lo with x == hi + mid + lo (to 2^-24 rel.).
- * planes: 3 * rows * 128 uint16 (bf16 bits), plane-major. */
-int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, void* hip_stream);
+/* Split `rows` x 128 fp32 into two fp16 planes hi/lo of x * 2^k, hi + lo == x * 2^k to 2^-22 relative.  k is one
+ * power of two per tensor, chosen from its absmax so that the scaled absmax lies in [2^14, 2^15) (no fp16 overflow, and
+ * the lo plane of every element that matters is a normal number).  planes: 2 * rows * 128 uint16 (fp16 bits),
+ * plane-major.  amax_bits: 1 uint32 on the device = bits of max|x| (the kernels derive k from it; keep it with the
+ * planes).  Three fp16 MFMA products lo*hi + hi*lo + hi*hi then give the fp32 dot product to below fp32 rounding noise. */
+int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, void* hip_stream);
 
 /* ---- A1: score_multi_vector_masked (evaluator/retrieval.py:166-213) ---------------------------------
  * out[q,p] = sum_n qmask[q,n] * has(p) * max_m( Q[q,n,:]·P[p,m,:] if pmask[p,m] else -1e4 )
@@ -73,9 +76,10 @@ int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const ui
                     const int64_t* strides_or_null,
                     void* workspace, size_t workspace_bytes, void* hip_stream);
 
-/* Same computation on a PREPARED (resident) corpus: bf16 planes + packed masks made once with
- * evdr_split_f32 / evdr_pack_pmask.  nplanes = 1 (bf16 corpus) or 3 (fp32 split).  Q planes are
- * (nplanes, nq, lq, 128) bf16; P planes are nplanes slabs `p_plane_stride` elements apart, each
+/* Same computation on a PREPARED (resident) corpus: planes + packed masks made once with
+ * evdr_split_f32 / evdr_pack_pmask.  nplanes = 1 (bf16 tensors as they are) or 2 (fp16 hi/lo planes of fp32
+ * tensors, with the absmax words evdr_split_f32 produced for Q and P; NULL = planes are unscaled).  Q planes are
+ * (nplanes, nq, lq, 128); P planes are nplanes slabs `p_plane_stride` elements apart, each
  * (np, lp, 128) with `p_stride` elements between pages.  out row stride = out_stride floats, so a
  * shard can write its column block of a wider (nq, N) matrix.  This is the bench / retrieval
  * hot path (SURVEY §8(d),(e)). */
@@ -84,6 +88,7 @@ int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes,
                              float* out, int64_t out_stride, uint16_t* argmax_or_null,
                              int64_t nq, int64_t lq, int64_t np, int64_t lp,
                              int nplanes, int64_t p_stride, int64_t p_plane_stride,
+                             const uint32_t* q_amax_or_null, const uint32_t* p_amax_or_null,
                              void* hip_stream);
 
 /* ---- A6: autograd of A1 w.r.t. P (loss.backward(), mainv2_iter_distill_infonce.py:290) ---------------
@@ -141,6 +146,7 @@ int evdr_maxsim_topk(const uint16_t* Qplanes, const uint16_t* Pplanes,
                      const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
                      int64_t nq, int64_t lq, int64_t np, int64_t lp,
                      int nplanes, int64_t p_stride, int64_t p_plane_stride,
+                     const uint32_t* q_amax_or_null, const uint32_t* p_amax_or_null,
                      int32_t idx_base, int k, float* top_scores, int32_t* top_idx,
                      void* workspace, size_t workspace_bytes, void* hip_stream);
 

@@ -123,7 +123,7 @@ def test_config3_100k_pages_properties(dev):
     msgs = []
     for r in range(8):                                                  # the 8-GPU sharding, replayed on one GPU
         lo, hi = shard_range(n, r, 8)
-        shard = PageCorpus(corpus.planes[:, lo:hi], corpus.tilemask[lo:hi], corpus.pageflags[lo:hi], idx_base=lo)
+        shard = corpus.shard(lo, hi)
         msgs.append(pack_candidates(*shard.topk(Q, None, k)))
     ms, mi = merge_candidates(*unpack_candidates(torch.stack(msgs)), k)
     assert torch.equal(mi, ti) and torch.equal(ms, ts)

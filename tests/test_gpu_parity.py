@@ -100,7 +100,7 @@ def test_a1_vs_oracle_shapes(dev, ER, nq, lq, lp):
 
 
 def test_a1_fp32_path_accuracy(dev, ER):
-    """fp32 inputs NOT representable in bf16: the 3-plane path must track an fp64 computation like fp32 does."""
+    """fp32 inputs NOT representable in 16 bits: the fp16 hi/lo path must track an fp64 computation like fp32 does."""
     gen = torch.Generator().manual_seed(77)
     Q = torch.nn.functional.normalize(torch.randn(16, 32, 128, generator=gen), dim=-1)
     P = torch.nn.functional.normalize(torch.randn(64, 300, 128, generator=gen), dim=-1)
@@ -113,6 +113,48 @@ def test_a1_fp32_path_accuracy(dev, ER):
     err_got, err_ref = (got - want).abs().max().item(), (ref32 - want).abs().max().item()
     assert err_got < 1e-5, err_got
     assert err_got < 10 * max(err_ref, 1e-6), (err_got, err_ref)
+
+
+def test_split_f32_planes(dev):
+    """evdr_split_f32: hi + lo == x * 2^k to 2^-21 relative, k from the absmax word, which holds the bits of max|x|."""
+    from evdr_amd import ops
+    gen = torch.Generator().manual_seed(78)
+    for scale in (1.0, 3e4, 2e-7):
+        x = (torch.randn(37, 19, 128, generator=gen) * scale).to(dev)
+        x[0, 0, :5] = 0.0
+        planes, amax = ops.split_f32(x)
+        assert planes.shape == (2, 37, 19, 128) and planes.dtype == torch.float16
+        bits = int(amax.item())
+        assert bits == int(x.abs().max().view(torch.int32).item())
+        k = 141 - ((bits >> 23) & 0xFF)
+        back = (planes[0].double() + planes[1].double()) * 2.0 ** (-k)
+        rel = ((back - x.double()).abs() / x.abs().max().double()).max().item()
+        assert torch.isfinite(planes.float()).all() and rel < 2.0 ** -21, (scale, rel)
+        assert planes[0].float().abs().max().item() < 2.0 ** 15 + 16
+    z, za = ops.split_f32(torch.zeros(4, 128, device=dev))
+    assert int(za.item()) == 0 and float(z.float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("qs,ps", [(1.0, 1.0), (4096.0, 1.0 / 8192.0), (1e-3, 37.5), (250.0, 250.0)])
+def test_a1_fp32_path_any_magnitude(dev, ER, qs, ps):
+    """fp32 inputs far from unit norm (the per-tensor power-of-two scaling of the fp16 planes): scores, argmax and the
+    -1e4 of masked patches in real units."""
+    gen = torch.Generator().manual_seed(79)
+    Q = torch.randn(11, 20, 128, generator=gen) * qs
+    P = torch.randn(23, 70, 128, generator=gen) * ps
+    qm = torch.rand(11, 20, generator=gen) > 0.2
+    pm = torch.rand(23, 70, generator=gen) > 0.3
+    pm[4] = False
+    pm[6, 40:] = False
+    sim = torch.einsum("qnd,pmd->qpnm", Q.double(), P.double()).masked_fill(~pm[None, :, None, :], -1e4)
+    mx, ix = sim.max(-1)
+    want = (mx * pm.any(-1)[None, :, None] * qm[:, None, :]).sum(-1)
+    from evdr_amd import ops
+    got, arg = ops.maxsim_forward(Q.to(dev), P.to(dev), qm.to(dev), pm.to(dev), want_argmax=True)
+    scale = float(want.abs().max())
+    assert (got.cpu().double() - want).abs().max().item() <= 2e-6 * scale
+    live = qm[:, None, :] & pm.any(-1)[None, :, None]
+    assert torch.equal(arg.cpu().long()[live], ix[live])
 
 
 def test_non_contiguous_and_nonbool_inputs(dev, ER):
@@ -325,7 +367,7 @@ def test_corpus_score_and_topk(dev):
     ts, ti = corpus.topk(Q.to(dev), qm.to(dev), 100)
     ws, wi = O.topk_rows(got.cpu(), 100)               # ranking of the device scores themselves: bit-exact
     assert torch.equal(ti.cpu(), wi + 1000) and torch.equal(ts.cpu(), ws)
-    # fp32 corpus (3 planes) with fp32 queries
+    # fp32 corpus (fp16 hi/lo planes) with fp32 queries
     c32 = PageCorpus.from_tensor(P.float().to(dev), pm.to(dev))
     got32 = c32.score(Q.float().to(dev), qm.to(dev))
     np.testing.assert_allclose(got32.cpu().numpy(), want.numpy(), atol=SCORE_ATOL)
