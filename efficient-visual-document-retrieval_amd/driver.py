@@ -2,7 +2,7 @@
 contract of the reference's `mainv2_iter_distill_infonce.py` (§5 "Metrics / logging").
 
 Not a port of that script: the step and the evaluation are organised around what is resident on the GPU.
-  * the frozen teacher pages are prepared ONCE as a resident corpus (bf16 hi/mid/lo planes + packed masks), so a
+  * the frozen teacher pages are prepared ONCE as a resident corpus (fp16 hi/lo planes + packed masks), so a
     step never re-reads or re-splits the 1030-patch fp32 teacher tensor (the reference re-uploads nothing but
     recomputes the teacher scores from fp32 every step, :283);
   * evaluation ranks on the device (top-100 per query, two D2H copies) instead of `.item()`-ing every score into
