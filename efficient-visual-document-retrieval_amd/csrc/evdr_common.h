@@ -43,6 +43,7 @@ struct EvdrFwdParams {
     int tok0, lq_total;         // lq_total = row length of qmask / argmax (queries longer than 32 tokens
     int accumulate;             //   are scored in 32-token slices, later slices add into out)
     int pages_per_block, n_qgroups, n_chunks;
+    int inblock_refill;         // staged kernel: issue the ring refill inside the MFMA block (else right after the barrier)
     unsigned long long* dbg;    // diagnostic builds only: per-wave cycle sums (null in production)
 };
 

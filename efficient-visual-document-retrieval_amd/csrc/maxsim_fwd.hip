@@ -30,5 +30,8 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
     const char* e = getenv("EVDR_FWD_VARIANT");
     const int variant = e ? atoi(e) : 0;
     if (variant == 5) qw = 1;                              // A/B: one query per wave
+    // HBM-bound launches (a handful of queries) want the refill in flight as early as possible: +3 % at 1-4 queries;
+    // everything else hides the refill's address work under MFMAs: +2..4 %
+    p.inblock_refill = p.nq > 4 ? 1 : 0;
     return evdr_launch_maxsim_fwd16(p, qw, nplanes, want_argmax, variant, stream);
 }

@@ -478,6 +478,7 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
     for (int i = 0; i < NSTAGE - 1; ++i)
         if (i < nstages) issue_stage(i, i);
     if constexpr (DIAG) d_pro = stamp() - d_t0;
+    const bool spread_ok = p.inblock_refill != 0;
     int slot = 0, S = 0;
     for (int pgi = 0; pgi < npages; ++pgi) {
         const int page = pg0 + pgi;
@@ -505,7 +506,7 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
             // scalar/address work hides under MFMAs; otherwise the refill is issued here, right after the barrier.
             const bool next_full = refill && (k + 1 < spp ? (k + 2) * ST * EVDR_TILE_PATCHES <= p.lp
                                                           : ST * EVDR_TILE_PATCHES <= p.lp);
-            const bool spread = SPREAD && fast && next_full;
+            const bool spread = SPREAD && fast && next_full && spread_ok;
             if (refill && !spread) issue_stage(S + NSTAGE - 1, nslot);
             if constexpr (DIAG) { const unsigned long long t = stamp(); d_ref += t - d_a; d_a = t; }
             const char* sbase = a_lane + slot * STAGE_BYTES;
