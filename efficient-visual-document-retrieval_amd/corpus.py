@@ -79,13 +79,8 @@ class PageCorpus:
         if nq == 0 or self.n_pages == 0:
             return view
         qp, qamax = self._query_planes(Q)
-        qm = ops._mask_u8(qmask, (nq, lq), dev)
-        lib = L.load()
-        with torch.cuda.device(dev):
-            L.check(lib.evdr_maxsim_fwd_prepared(
-                L.ptr(qp), L.ptr(self.planes), L.ptr(qm), L.ptr(self.tilemask), L.ptr(self.pageflags),
-                view.data_ptr(), out.stride(0), None, nq, lq, self.n_pages, self.lp, self.nplanes,
-                self.p_stride, self.p_plane_stride, L.ptr(qamax), L.ptr(self.amax), L.current_stream_handle(dev)))
+        ops.maxsim_forward_prepared(qp, qamax, self.planes, self.amax, qmask, self.tilemask, self.pageflags, out=out,
+                                    out_col=out_col)
         return view
 
     def topk(self, Q: torch.Tensor, qmask: Optional[torch.Tensor], k: int) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -233,8 +233,20 @@ int evdr_l2norm_fwd(const float* x, const uint8_t* rowmask_or_null, int64_t rows
     if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported", (long long)d);
     if (rows == 0) return EVDR_OK;
     if (!x || !y) return fail(EVDR_ERR_ARG, "evdr_l2norm_fwd: null pointer");
-    hipError_t e = evdr_launch_l2norm_fwd(x, rowmask_or_null, rows, eps, y, norm_or_null, (hipStream_t)hip_stream);
+    hipError_t e = evdr_launch_l2norm_fwd(x, rowmask_or_null, rows, eps, y, norm_or_null, nullptr, nullptr, (hipStream_t)hip_stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "l2norm_fwd launch");
+}
+
+int evdr_l2norm_fwd_split(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps, float* y_or_null,
+                          float* norm_or_null, uint16_t* planes, uint32_t* amax_bits, void* hip_stream) {
+    if (rows < 0) return fail(EVDR_ERR_ARG, "negative rows");
+    if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported", (long long)d);
+    if (!amax_bits) return fail(EVDR_ERR_ARG, "evdr_l2norm_fwd_split: null amax_bits");
+    if (rows == 0) return EVDR_OK;
+    if (!x || !planes) return fail(EVDR_ERR_ARG, "evdr_l2norm_fwd_split: null pointer");
+    hipError_t e = evdr_launch_l2norm_fwd(x, rowmask_or_null, rows, eps, y_or_null, norm_or_null, planes, amax_bits,
+                                          (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "l2norm_fwd_split launch");
 }
 
 int evdr_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask_or_null, const float* norm, int64_t rows,

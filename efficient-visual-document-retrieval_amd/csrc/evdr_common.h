@@ -106,7 +106,7 @@ hipError_t evdr_launch_maxsim_bwd_q(const float* g, const float* P, const uint8_
                                     const uint16_t* argmax, float* dQ, int64_t nq, int64_t lq, int64_t np, int64_t lp,
                                     hipStream_t stream);
 hipError_t evdr_launch_l2norm_fwd(const float* x, const uint8_t* rowmask, int64_t rows, float eps, float* y, float* norm,
-                                  hipStream_t stream);
+                                  uint16_t* planes, uint32_t* amax_bits, hipStream_t stream);
 hipError_t evdr_launch_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask, const float* norm, int64_t rows,
                                   float eps, float* dx, hipStream_t stream);
 hipError_t evdr_launch_topk(const float* scores, const int32_t* idx_map, int64_t nq, int64_t n,

@@ -237,10 +237,17 @@ __global__ void __launch_bounds__(256) maxsim_bwd_q_kernel(const float* __restri
 // ---- l2_normalize (utils/preprocess_data.py:8-9) with an optional per-row mask, forward and backward ---------------
 // y = m * x / (||m*x|| + eps);  one 16-lane group per 128-wide row (8 floats per lane, two 16-B accesses).
 // backward of y = x/(n + eps):  dx = g/(n+eps) - x * (x.g) / (n (n+eps)^2)   (n > 0; the norm's subgradient at 0 is 0)
+// SPLIT: also (or only, y == null) emit y as the fp16 hi/lo planes the forward kernel reads (evdr_split_f32's format).
+// |y| <= 1 by construction, so the scale is the constant 2^14 and the absmax word is that of 1.0f: no absmax pass and no
+// second trip of the normalised pages through HBM on the training step.
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) l2norm_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ rowmask,
                                                         int64_t rows, float eps, float* __restrict__ y,
-                                                        float* __restrict__ norm) {
+                                                        float* __restrict__ norm, _Float16* __restrict__ hi,
+                                                        _Float16* __restrict__ lo, uint32_t* __restrict__ amax_bits) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
     const int sub = threadIdx.x & 15;
+    if (SPLIT && blockIdx.x == 0 && threadIdx.x == 0) *amax_bits = 0x3F800000u;
     for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < rows; r += (int64_t)gridDim.x * 16) {
         const float m = (rowmask == nullptr || rowmask[r] != 0) ? 1.f : 0.f;
         f32x4 v0 = *reinterpret_cast<const f32x4*>(x + r * EVDR_D + sub * 8);
@@ -252,9 +259,26 @@ __global__ void __launch_bounds__(256) l2norm_fwd_kernel(const float* __restrict
         for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
         const float n = sqrtf(ss);
         const float inv = 1.f / (n + eps);
-        *reinterpret_cast<f32x4*>(y + r * EVDR_D + sub * 8) = v0 * inv;
-        *reinterpret_cast<f32x4*>(y + r * EVDR_D + sub * 8 + 4) = v1 * inv;
+        v0 *= inv;
+        v1 *= inv;
+        if (y != nullptr) {
+            *reinterpret_cast<f32x4*>(y + r * EVDR_D + sub * 8) = v0;
+            *reinterpret_cast<f32x4*>(y + r * EVDR_D + sub * 8 + 4) = v1;
+        }
         if (sub == 0 && norm != nullptr) norm[r] = n;
+        if constexpr (SPLIT) {
+            constexpr int K = 141 - 127;              // evdr_h2_shift(bits of 1.0f)
+            f16x8 a, b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = __builtin_ldexpf((j < 4) ? v0[j & 3] : v1[j & 3], K);
+                const _Float16 h = (_Float16)f;
+                a[j] = h;
+                b[j] = (_Float16)(f - (float)h);
+            }
+            *reinterpret_cast<f16x8*>(hi + r * EVDR_D + sub * 8) = a;
+            *reinterpret_cast<f16x8*>(lo + r * EVDR_D + sub * 8) = b;
+        }
     }
 }
 
@@ -402,11 +426,16 @@ hipError_t evdr_launch_maxsim_bwd_q(const float* g, const float* P, const uint8_
 }
 
 hipError_t evdr_launch_l2norm_fwd(const float* x, const uint8_t* rowmask, int64_t rows, float eps, float* y, float* norm,
-                                  hipStream_t stream) {
+                                  uint16_t* planes, uint32_t* amax_bits, hipStream_t stream) {
     if (rows == 0) return hipSuccess;
     int64_t blocks = (rows + 15) / 16;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, rowmask, rows, eps, y, norm);
+    if (planes != nullptr)
+        hipLaunchKernelGGL(l2norm_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, x, rowmask, rows, eps, y, norm,
+                           (_Float16*)planes, (_Float16*)planes + rows * EVDR_D, amax_bits);
+    else
+        hipLaunchKernelGGL(l2norm_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, x, rowmask, rows, eps, y, norm,
+                           (_Float16*)nullptr, (_Float16*)nullptr, (uint32_t*)nullptr);
     return hipGetLastError();
 }
 

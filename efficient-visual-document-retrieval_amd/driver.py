@@ -307,14 +307,19 @@ class FusedStudent:
         self.exp_avg_sq = torch.zeros_like(self.x)
         self.lr, self.weight_decay, self.betas, self.eps, self.l2_eps = lr, weight_decay, betas, eps, l2_eps
         self.steps = 0
+        npg, ls, _ = self.x.shape
+        self.tilemask, self.pageflags = ops.pack_pmask(self.pmask, npg, ls, self.x.device)     # the mask never changes
 
     def normalized(self) -> torch.Tensor:
         return ops.l2norm_forward(self.x, self.pmask, self.l2_eps)[0]
 
     def update(self, Qb, qmb, sc_t, temp: float) -> torch.Tensor:
         """One step given the teacher scores; returns the loss as a device scalar (no host sync)."""
-        Psb = self.normalized()
-        sc_s, arg = ops.maxsim_forward(Qb, Psb, qmb, self.pmask, want_argmax=True)
+        # l2_normalize(Pbar * pmask) lands directly in the scorer's fp16 hi/lo planes (no fp32 copy, no absmax/split pass)
+        pplanes, pamax = ops.l2norm_split(self.x, self.pmask, self.l2_eps)
+        qplanes, qamax = ops.split_f32(Qb)
+        sc_s, arg = ops.maxsim_forward_prepared(qplanes, qamax, pplanes, pamax, qmb, self.tilemask, self.pageflags,
+                                                want_argmax=True)
         loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True)
         self.steps += 1
         ops.maxsim_backward_adamw(dscore, Qb, qmb, self.pmask, arg, self.x, self.exp_avg, self.exp_avg_sq, self.lr,

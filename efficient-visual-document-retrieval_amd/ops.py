@@ -113,6 +113,37 @@ def maxsim_forward(Q: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Tenso
     return out, arg
 
 
+def maxsim_forward_prepared(qplanes: torch.Tensor, qamax: Optional[torch.Tensor], pplanes: torch.Tensor,
+                            pamax: Optional[torch.Tensor], qmask: Optional[torch.Tensor], tilemask: torch.Tensor,
+                            pageflags: torch.Tensor, want_argmax: bool = False, out: Optional[torch.Tensor] = None,
+                            out_col: int = 0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """A1 on PREPARED operands (evdr_maxsim_fwd_prepared): planes from `split_f32` / `l2norm_split` (2 fp16 planes + absmax
+    word) or bf16 tensors with a leading plane axis of 1, masks from `pack_pmask`.  Nothing is converted or packed here.
+    With `out` (nq, >= out_col + np) given, the scores land in out[:, out_col:out_col+np] (a shard's column block)."""
+    dev = _require_cuda(qplanes, pplanes)
+    nplanes, nq, lq, _ = qplanes.shape
+    _, npg, lp, _ = pplanes.shape
+    if pplanes.shape[0] != nplanes or (nplanes == 2) != (qplanes.dtype == torch.float16) or pplanes.dtype != qplanes.dtype:
+        raise RuntimeError("query and page planes must both be (1, ., ., 128) bf16 or both (2, ., ., 128) fp16")
+    if pplanes.stride(3) != 1 or pplanes.stride(2) != D or not qplanes.is_contiguous():
+        raise RuntimeError("planes must be dense in their last two dims (queries fully contiguous)")
+    if out is None:
+        out = torch.empty((nq, npg), dtype=torch.float32, device=dev)
+        out_col = 0
+    view = out[:, out_col:out_col + npg]
+    arg = torch.empty((nq, npg, lq), dtype=torch.int16, device=dev) if want_argmax else None
+    if nq == 0 or npg == 0:
+        return view, arg
+    qm = _mask_u8(qmask, (nq, lq), dev)
+    lib = L.load()
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_maxsim_fwd_prepared(
+            L.ptr(qplanes), L.ptr(pplanes), L.ptr(qm), L.ptr(tilemask), L.ptr(pageflags), view.data_ptr(), out.stride(0),
+            L.ptr(arg), nq, lq, npg, lp, nplanes, int(pplanes.stride(1)), int(pplanes.stride(0)), L.ptr(qamax), L.ptr(pamax),
+            L.current_stream_handle(dev)))
+    return view, arg
+
+
 def maxsim_backward(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],
                     argmax: torch.Tensor, npg: int, lp: int) -> torch.Tensor:
     """A6: dP (np, lp, 128) fp32 from upstream g (nq, np) and the forward's argmax."""
@@ -188,6 +219,24 @@ def l2norm_forward(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float)
         L.check(lib.evdr_l2norm_fwd(L.ptr(xc), L.ptr(m), rows, D, float(eps), L.ptr(y), L.ptr(norm),
                                     L.current_stream_handle(dev)))
     return y, norm
+
+
+def l2norm_split(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """y = m*x / (||m*x|| + eps) emitted directly as the scorer's fp16 hi/lo planes (see `split_f32`): ((2, ..., 128) fp16,
+    absmax word).  One kernel instead of normalise -> absmax -> split, and no fp32 copy of y in HBM."""
+    dev = _require_cuda(x)
+    if x.shape[-1] != D or x.dtype != torch.float32:
+        raise RuntimeError("l2norm kernel needs fp32 rows of width 128")
+    lib = L.load()
+    xc = x.contiguous()
+    rows = xc.numel() // D
+    planes = torch.empty((2,) + tuple(xc.shape), dtype=torch.float16, device=dev)
+    amax = torch.empty((1,), dtype=torch.int32, device=dev)
+    m = _mask_u8(rowmask, xc.shape[:-1], dev)
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_l2norm_fwd_split(L.ptr(xc), L.ptr(m), rows, D, float(eps), None, None, L.ptr(planes), L.ptr(amax),
+                                          L.current_stream_handle(dev)))
+    return planes, amax
 
 
 def l2norm_backward(gy: torch.Tensor, x: torch.Tensor, rowmask: Optional[torch.Tensor], norm: torch.Tensor,

@@ -130,6 +130,13 @@ int evdr_l2norm_fwd(const float* x, const uint8_t* rowmask_or_null, int64_t rows
                     float* y, float* norm_or_null, void* hip_stream);
 int evdr_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask_or_null, const float* norm,
                     int64_t rows, int64_t d, float eps, float* dx, void* hip_stream);
+/* evdr_l2norm_fwd that also (or only: y_or_null = NULL) emits y in evdr_split_f32's format -- fp16 hi/lo planes
+ * (2 * rows * 128 uint16) + the absmax word, here the constant bits of 1.0f since |y| <= 1 -- ready for
+ * evdr_maxsim_fwd_prepared(nplanes = 2): the normalised student pages of a training step go to the scorer without an
+ * fp32 round trip through HBM (mainv2_iter_distill_infonce.py:279-283). */
+int evdr_l2norm_fwd_split(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps,
+                          float* y_or_null, float* norm_or_null, uint16_t* planes, uint32_t* amax_bits,
+                          void* hip_stream);
 
 /* ---- A8: top-k per query row, replaces the Nq*N .item() loop (mainv2_iter_distill_infonce.py:311-317)
  * scores (nq, n) fp32 with row stride `row_stride`; idx_map_or_null (nq, n) int32 maps a column to

@@ -135,6 +135,28 @@ def test_split_f32_planes(dev):
     assert int(za.item()) == 0 and float(z.float().abs().max()) == 0.0
 
 
+def test_l2norm_split_planes(dev):
+    """evdr_l2norm_fwd_split: the planes it writes decode to l2_normalize(x * mask), and score like the fp32 tensor."""
+    from evdr_amd import ops
+    gen = torch.Generator().manual_seed(80)
+    x = (torch.randn(9, 50, 128, generator=gen) * 3.0).to(dev)
+    m = (torch.rand(9, 50, generator=gen) > 0.25).to(dev)
+    x[2, 7] = 0.0                                                   # zero row stays exactly zero
+    y, _ = ops.l2norm_forward(x, m, 1e-12)
+    planes, amax = ops.l2norm_split(x, m, 1e-12)
+    assert int(amax.item()) == 0x3F800000
+    back = (planes[0].double() + planes[1].double()) * 2.0 ** -14
+    assert (back - y.double()).abs().max().item() < 2.0 ** -22
+    assert float(back[2, 7].abs().max()) == 0.0 and float(back[~m].abs().max()) == 0.0
+    Q = torch.nn.functional.normalize(torch.randn(5, 12, 128, generator=gen), dim=-1).to(dev)
+    qp, qa = ops.split_f32(Q)
+    tm, pf = ops.pack_pmask(m, 9, 50, dev)
+    got, arg = ops.maxsim_forward_prepared(qp, qa, planes, amax, None, tm, pf, want_argmax=True)
+    want, warg = ops.maxsim_forward(Q, y, None, m, want_argmax=True)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-6)
+    assert torch.equal(arg, warg)
+
+
 @pytest.mark.parametrize("qs,ps", [(1.0, 1.0), (4096.0, 1.0 / 8192.0), (1e-3, 37.5), (250.0, 250.0)])
 def test_a1_fp32_path_any_magnitude(dev, ER, qs, ps):
     """fp32 inputs far from unit norm (the per-tensor power-of-two scaling of the fp16 planes): scores, argmax and the
