@@ -115,6 +115,28 @@ def test_a1_fp32_path_accuracy(dev, ER):
     assert err_got < 10 * max(err_ref, 1e-6), (err_got, err_ref)
 
 
+@pytest.mark.parametrize("nq", [5, 8, 9, 13, 16])
+@pytest.mark.parametrize("lp", [256, 300, 1030])
+def test_a1_few_queries_long_pages(dev, ER, nq, lp):
+    """5..16 bf16 queries against long pages (partly idle workgroups of the staged kernel): prefix masks, holes, an
+    all-masked page, ragged query masks, several pages per workgroup."""
+    gen = torch.Generator().manual_seed(1000 + 17 * nq + lp)
+    npg = 37
+    Q = torch.nn.functional.normalize(torch.randn(nq, 32, 128, generator=gen), dim=-1).bfloat16()
+    P = torch.nn.functional.normalize(torch.randn(npg, lp, 128, generator=gen), dim=-1).bfloat16()
+    qm = torch.rand(nq, 32, generator=gen) > 0.15
+    pm = torch.ones(npg, lp, dtype=torch.bool)
+    pm[3] = False
+    pm[5, lp // 2:] = False
+    pm[6, 17:] = False
+    pm[9] = torch.rand(lp, generator=gen) > 0.4
+    pm[20, : lp - 3] = False
+    want = O.maxsim_masked(Q.float(), P.float(), qm, pm)
+    got = ER.score_multi_vector_masked(Q.to(dev), P.to(dev), qm.to(dev), pm.to(dev))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=SCORE_ATOL)
+    assert got[:, 3].abs().max().item() == 0.0
+
+
 def test_split_f32_planes(dev):
     """evdr_split_f32: hi + lo == x * 2^k to 2^-21 relative, k from the absmax word, which holds the bits of max|x|."""
     from evdr_amd import ops
