@@ -196,7 +196,7 @@ def main():
             traffic = None
     roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                "kernel": "maxsim_fwd16s_kernel<QW=4,ST=8,NSTAGE=2,BAL>", "kernel_ms": k_ms,
+                "kernel": "maxsim_fwd16s_kernel<QW=4,NPL=1,ARGMAX=0,ST=8,NSTAGE=2,BAL>", "kernel_ms": k_ms,
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "algorithmic_bytes_per_launch": corpus.n_pages * LP * D * 2}
 
