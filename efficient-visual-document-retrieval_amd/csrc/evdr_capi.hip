@@ -56,14 +56,18 @@ int check_common(int64_t nq, int64_t lq, int64_t np, int64_t lp) {
 }
 
 // Runs the forward over 32-token slices of the queries (one slice for Lq <= 32).
+// Single-token queries (Lq = 1: the "virtual queries" of mainv3_iter_liscore_QA_hardtoken.py:428-434) would leave 31 of
+// the 32 token lanes of the MFMA tile empty; dense (nq, 1, 128) rows ARE the layout of ceil(nq/32) queries of 32 tokens,
+// so they are scored as such with one output row per token (EvdrFwdParams::per_token): 32x less MFMA work.
 int run_fwd(const uint16_t* Qp, int64_t q_stride, int64_t q_plane_stride, const uint16_t* Pp, int64_t p_stride,
             int64_t p_plane_stride, const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
             float* out, int64_t out_stride, uint16_t* argmax, int64_t nq, int64_t lq, int64_t np, int64_t lp,
             int nplanes, const uint32_t* q_amax, const uint32_t* p_amax, hipStream_t stream) {
+    const bool pack = (lq == 1 && nq > 1 && q_stride == EVDR_D);
     for (int64_t tok0 = 0; tok0 < lq; tok0 += 32) {
         EvdrFwdParams p{};
         p.Q = Qp;
-        p.q_stride = q_stride;
+        p.q_stride = pack ? 32 * EVDR_D : q_stride;
         p.q_plane_stride = q_plane_stride;
         p.P = Pp;
         p.p_stride = p_stride;
@@ -76,12 +80,13 @@ int run_fwd(const uint16_t* Qp, int64_t q_stride, int64_t q_plane_stride, const 
         p.out = out;
         p.out_stride = out_stride;
         p.argmax = argmax;
-        p.nq = (int)nq;
-        p.lq = (int)((lq - tok0 < 32) ? (lq - tok0) : 32);
+        p.nq = (int)(pack ? (nq + 31) / 32 : nq);
+        p.lq = pack ? 32 : (int)((lq - tok0 < 32) ? (lq - tok0) : 32);
         p.np = (int)np;
         p.lp = (int)lp;
         p.tok0 = (int)tok0;
-        p.lq_total = (int)lq;
+        p.lq_total = pack ? 32 : (int)lq;
+        p.per_token = pack ? nq : 0;
         p.accumulate = tok0 > 0 ? 1 : 0;
         hipError_t e = evdr_launch_maxsim_fwd(p, nplanes, argmax != nullptr, stream);
         if (e != hipSuccess) return hip_fail(e, "maxsim_fwd launch");

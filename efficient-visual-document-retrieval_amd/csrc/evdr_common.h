@@ -43,6 +43,8 @@ struct EvdrFwdParams {
     int tok0, lq_total;         // lq_total = row length of qmask / argmax (queries longer than 32 tokens
     int accumulate;             //   are scored in 32-token slices, later slices add into out)
     int pages_per_block, n_qgroups, n_chunks;
+    int64_t per_token;          // > 0: Q holds this many SINGLE-token queries packed 32 to a "query"; out / argmax get one
+                                //      row per token (out (per_token, np), argmax (per_token, np)) instead of the token sum
     int inblock_refill;         // staged kernel: issue the ring refill inside the MFMA block (else right after the barrier)
     unsigned long long* dbg;    // diagnostic builds only: per-wave cycle sums (null in production)
 };

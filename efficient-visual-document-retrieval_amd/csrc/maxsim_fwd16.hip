@@ -316,7 +316,8 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int tok = 16 * t + c;
-            const bool ok = (q < p.nq) && (tok < p.lq);
+            // per_token: "query" q is the pack of single-token queries 32 q .. 32 q + 31, the last pack may be short
+            const bool ok = (q < p.nq) && (tok < p.lq) && (!p.per_token || (int64_t)q * 32 + tok < p.per_token);
             const int64_t row = (int64_t)q * p.q_stride + (int64_t)(p.tok0 + tok) * EVDR_D + g * 8;
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl)
@@ -665,13 +666,23 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                             bi = take ? fm : bi;
                         }
                     }
+                    const int tok = 16 * t + c;
+                    if (p.per_token) {
+                        // packed single-token queries: one score (and argmax) per token, no sum over the pack
+                        const int64_t qrow = (int64_t)(q0 + j) * 32 + tok;
+                        if (g == 0 && q0 + j < p.nq && qrow < p.per_token) {
+                            p.out[qrow * p.out_stride + page] = v * has * qwt[j][t];
+                            if constexpr (ARGMAX) p.argmax[qrow * p.np + page] = (uint16_t)bi;
+                        }
+                        continue;
+                    }
                     if constexpr (ARGMAX) {
-                        const int tok = 16 * t + c;
                         if (g == 0 && tok < p.lq && q0 + j < p.nq)
                             p.argmax[((int64_t)(q0 + j) * p.np + page) * p.lq_total + p.tok0 + tok] = (uint16_t)bi;
                     }
                     cs += v * has * qwt[j][t];
                 }
+                if (p.per_token) continue;
                 cs = row16_sum(cs);
                 if (lane == 0 && q0 + j < p.nq) {
                     float* o = p.out + (int64_t)(q0 + j) * p.out_stride + page;
@@ -737,7 +748,7 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes,
     }
     if (geom == 2 && ntiles >= 8 && qw == 4) return launch16s<4, 1, false, 8, 2, false, false>(p, stream);   // A/B: no priority schedule
     if (geom == 4 && ntiles >= 8 && qw == 1) return launch16s<1, 1, false, 4, 2, false, false, 4>(p, stream);  // A/B: 2 WGs per CU
-    if (geom != 1 && geom != 3 && geom != 4 && ntiles >= 8) {
+    if ((geom != 1 && geom != 3 && geom != 4 && ntiles >= 8) || p.per_token) {
         if (qw == 4) return launch16s<4, 1, false, 8, 2, false, true>(p, stream);
         if (qw == 2) return launch16s<2, 1, false, 8, 2, false, true>(p, stream);
         return launch16s<1, 1, false, 8, 2, false, true>(p, stream);

@@ -68,7 +68,9 @@ int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* ama
  * (NULL = dense).  qmask (nq,lq) / pmask (np,lp) bytes; either may be NULL = all valid.
  * out (nq,np) fp32 dense.  argmax_or_null: (nq,np,lq) uint16, first maximal patch index per
  * query token (what torch.max picks, :201) -- needed only for evdr_maxsim_bwd.
- * chunk_p of the reference is a memory knob with no numerical effect and has no counterpart. */
+ * chunk_p of the reference is a memory knob with no numerical effect and has no counterpart.
+ * lq == 1 with dense queries (the single-token "virtual queries" of mainv3_iter_liscore_QA_hardtoken.py:428-434) is
+ * scored 32 queries to an MFMA tile internally; shapes and results are those of the general case. */
 size_t evdr_maxsim_fwd_workspace(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype);
 int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const uint8_t* pmask,
                     float* out, uint16_t* argmax_or_null,

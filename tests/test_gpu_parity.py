@@ -137,6 +137,38 @@ def test_a1_few_queries_long_pages(dev, ER, nq, lp):
     assert got[:, 3].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("nq", [1, 2, 31, 32, 33, 70])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_a1_single_token_queries(dev, ER, nq, bf16):
+    """Lq = 1 "virtual queries" (mainv3_iter_liscore_QA_hardtoken.py:428-434): scored 32 to an MFMA tile with one output
+    row per token; forward, argmax and both gradients against the oracle."""
+    gen = torch.Generator().manual_seed(500 + nq)
+    npg, lp = 19, 77
+    Q = torch.nn.functional.normalize(torch.randn(nq, 1, 128, generator=gen), dim=-1)
+    P = torch.nn.functional.normalize(torch.randn(npg, lp, 128, generator=gen), dim=-1)
+    if bf16:
+        Q, P = Q.bfloat16().float(), P.bfloat16().float()
+    qm = torch.rand(nq, 1, generator=gen) > 0.2
+    pm = torch.rand(npg, lp, generator=gen) > 0.3
+    pm[2] = False
+    pm[4, 30:] = False
+    want, warg = O.maxsim_masked_argmax(Q, P, qm, pm)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    from evdr_amd import ops
+    got, arg = ops.maxsim_forward(Q.to(dev, dt), P.to(dev, dt), qm.to(dev), pm.to(dev), want_argmax=True)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=SCORE_ATOL)
+    live = qm[:, None, :] & pm.any(-1)[None, :, None]
+    assert torch.equal(arg.cpu().long()[live], warg.long()[live])
+    Pd = P.to(dev).requires_grad_(True)
+    Qd = Q.to(dev).requires_grad_(True)
+    gsc = torch.randn(nq, npg, generator=gen)
+    ER.score_multi_vector_masked(Qd, Pd, qm.to(dev), pm.to(dev)).backward(gsc.to(dev))
+    Pc, Qc = P.clone().requires_grad_(True), Q.clone().requires_grad_(True)
+    O.maxsim_masked(Qc, Pc, qm, pm).backward(gsc)
+    np.testing.assert_allclose(Pd.grad.cpu().numpy(), Pc.grad.numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(Qd.grad.cpu().numpy(), Qc.grad.numpy(), atol=2e-5, rtol=1e-5)
+
+
 def test_split_f32_planes(dev):
     """evdr_split_f32: hi + lo == x * 2^k to 2^-21 relative, k from the absmax word, which holds the bits of max|x|."""
     from evdr_amd import ops
