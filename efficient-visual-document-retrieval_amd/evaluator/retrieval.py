@@ -14,6 +14,8 @@ Reference lines mirrored:
 """
 from __future__ import annotations
 
+import collections
+import weakref
 from abc import ABC, abstractmethod
 from typing import Dict, List, Optional, Tuple, Union
 
@@ -23,7 +25,7 @@ from .. import ops
 from . import metrics as _metrics
 
 __all__ = ["get_torch_device", "BaseVisualRetrieverProcessor", "score_multi_vector_masked",
-           "CustomRetrievalEvaluator"]
+           "CustomRetrievalEvaluator", "forget_prepared"]
 
 
 def get_torch_device(device: str = "auto") -> str:
@@ -33,6 +35,45 @@ def get_torch_device(device: str = "auto") -> str:
     return device
 
 
+# Frozen fp32 pages (the teacher of a training run, the corpus of repeated evaluations) arrive here unchanged call after
+# call (mainv2_iter_distill_infonce.py:282-283 re-scores P_teacher_norm every step).  Their device-side preparation --
+# absmax + fp16 hi/lo split + mask packing, three passes over the pages -- is kept per tensor and reused while the tensor
+# is alive and its autograd version counter has not moved (in-place torch ops bump it; so do this package's own in-place
+# kernels).  Writes through raw pointers by other libraries are not seen: call `forget_prepared()` after such a write.
+_PREPARED: "collections.OrderedDict" = collections.OrderedDict()
+_PREPARED_MAX = 4                      # tensors
+_PREPARED_MAX_BYTES = 32 << 30         # of prepared planes in total (they are as large as the fp32 pages themselves)
+
+
+def forget_prepared() -> None:
+    _PREPARED.clear()
+
+
+def _tensor_key(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t.device.index, t._version)
+
+
+def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
+    """(planes, amax, tilemask, pageflags) of frozen fp32-like pages, from the cache when P and pmask are unchanged."""
+    key = (_tensor_key(P), _tensor_key(pmask))
+    hit = _PREPARED.get(key)
+    if hit is not None and hit[0]() is not None and (pmask is None or hit[1]() is not None):
+        _PREPARED.move_to_end(key)
+        return hit[2]
+    planes, amax = ops.split_f32(P)
+    tilemask, pageflags = ops.pack_pmask(pmask, P.shape[0], P.shape[1], P.device)
+    prep = (planes, amax, tilemask, pageflags)
+    nbytes = planes.numel() * planes.element_size()
+    if nbytes <= _PREPARED_MAX_BYTES:
+        drop = lambda _ref, key=key: _PREPARED.pop(key, None)          # the tensor died: free its planes right away
+        _PREPARED[key] = (weakref.ref(P, drop), weakref.ref(pmask, drop) if pmask is not None else None, prep, nbytes)
+        while len(_PREPARED) > _PREPARED_MAX or sum(e[3] for e in _PREPARED.values()) > _PREPARED_MAX_BYTES:
+            _PREPARED.popitem(last=False)
+    return prep
+
+
 # ------------------------------------------------------------------------------------------------
 # A1 + A6: masked MaxSim, differentiable w.r.t. the page embeddings
 # ------------------------------------------------------------------------------------------------
@@ -40,7 +81,16 @@ class _MaxSimMasked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Q, P, qmask, pmask):
         need_dq, need_dp = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        out, arg = ops.maxsim_forward(Q, P, qmask, pmask, want_argmax=need_dp or need_dq)
+        frozen = (not need_dp and P.is_cuda and P.dim() == 3 and Q.dim() == 3 and P.shape[-1] == ops.D and Q.shape[-1] == ops.D
+                  and not (P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16) and P.shape[0] > 0 and P.shape[1] > 0
+                  and Q.shape[0] > 0 and Q.shape[1] > 0 and P.shape[1] <= 65535 and Q.shape[1] <= 65535)
+        if frozen:
+            planes, amax, tilemask, pageflags = _prepared_pages(P, pmask)
+            qplanes, qamax = ops.split_f32(Q)
+            out, arg = ops.maxsim_forward_prepared(qplanes, qamax, planes, amax, qmask, tilemask, pageflags,
+                                                   want_argmax=need_dq)
+        else:
+            out, arg = ops.maxsim_forward(Q, P, qmask, pmask, want_argmax=need_dp or need_dq)
         if need_dp or need_dq:
             ctx.save_for_backward(Q.detach(), P.detach() if need_dq else None, qmask, pmask, arg)
             ctx.p_shape, ctx.p_dtype, ctx.q_dtype = tuple(P.shape), P.dtype, Q.dtype

@@ -273,6 +273,8 @@ def maxsim_backward_adamw(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torc
                                           L.ptr(exp_avg_sq), nq, lq, npg, lp, d, float(lr), float(betas[0]), float(betas[1]),
                                           float(eps), float(weight_decay), int(step), float(l2_eps),
                                           L.current_stream_handle(dev)))
+    for t in (x, exp_avg, exp_avg_sq):            # written through raw pointers: tell autograd (and version-keyed caches)
+        torch.autograd.graph.increment_version(t)
 
 
 def maxsim_backward_q(g: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],

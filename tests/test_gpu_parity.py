@@ -169,6 +169,41 @@ def test_a1_single_token_queries(dev, ER, nq, bf16):
     np.testing.assert_allclose(Qd.grad.cpu().numpy(), Qc.grad.numpy(), atol=2e-5, rtol=1e-5)
 
 
+def test_prepared_pages_cache(dev, ER):
+    """Frozen fp32 pages are prepared once per tensor; any in-place change (version counter) or a new tensor re-prepares."""
+    gen = torch.Generator().manual_seed(81)
+    Q = torch.nn.functional.normalize(torch.randn(6, 16, 128, generator=gen), dim=-1).to(dev)
+    P = torch.nn.functional.normalize(torch.randn(12, 60, 128, generator=gen), dim=-1).to(dev)
+    pm = (torch.rand(12, 60, generator=gen) > 0.2).to(dev)
+    qm = torch.ones(6, 16, dtype=torch.bool, device=dev)
+    ER.forget_prepared()
+    a = ER.score_multi_vector_masked(Q, P, qm, pm)
+    assert len(ER._PREPARED) == 1
+    b = ER.score_multi_vector_masked(Q, P, qm, pm)                       # hit
+    assert len(ER._PREPARED) == 1 and torch.equal(a, b)
+    np.testing.assert_allclose(a.cpu().numpy(), O.maxsim_masked(Q.cpu(), P.cpu(), qm.cpu(), pm.cpu()).numpy(), atol=SCORE_ATOL)
+    P.mul_(-1.0)                                                          # in-place change: must not hit the stale planes
+    c = ER.score_multi_vector_masked(Q, P, qm, pm)
+    np.testing.assert_allclose(c.cpu().numpy(), O.maxsim_masked(Q.cpu(), P.cpu(), qm.cpu(), pm.cpu()).numpy(), atol=SCORE_ATOL)
+    pm[0] = False                                                         # so does a change of the mask
+    d = ER.score_multi_vector_masked(Q, P, qm, pm)
+    assert d[:, 0].abs().max().item() == 0.0
+    Pg = P.clone().requires_grad_(True)                                   # trainable pages never go through the cache
+    n0 = len(ER._PREPARED)
+    ER.score_multi_vector_masked(Q, Pg, qm, pm).sum().backward()
+    assert len(ER._PREPARED) == n0 and Pg.grad is not None
+    Qg = Q.clone().requires_grad_(True)                                   # frozen pages, trainable queries: dQ through the cache path
+    ER.score_multi_vector_masked(Qg, P, qm, pm).sum().backward()
+    Qc = Q.cpu().clone().requires_grad_(True)
+    O.maxsim_masked(Qc, P.cpu(), qm.cpu(), pm.cpu()).sum().backward()
+    np.testing.assert_allclose(Qg.grad.cpu().numpy(), Qc.grad.numpy(), atol=2e-5, rtol=1e-5)
+    del P, a, b, c, d
+    import gc
+    gc.collect()
+    assert all(e[0]() is not None for e in ER._PREPARED.values())         # entries of dead tensors are dropped at once
+    ER.forget_prepared()
+
+
 def test_split_f32_planes(dev):
     """evdr_split_f32: hi + lo == x * 2^k to 2^-21 relative, k from the absmax word, which holds the bits of max|x|."""
     from evdr_amd import ops
