@@ -3,7 +3,8 @@
 shape -- 32 queries x 32 tokens, N = 500 pages, teacher 1030 patches, student 206 patches (mf5), fp32 parameters,
 temperature 0.1, AdamW(lr 1e-3, wd 1e-2).  Reports ms/step of the drop-in functions used exactly like
 mainv2_iter_distill_infonce.py:269-292 ("call_pattern"), of the driver's resident-teacher step ("resident") and of
-the same with cached teacher scores ("cached"); `--eager` adds a plain torch restatement of the reference's four
+the same with cached teacher scores ("cached"), of the fused student update ("fused", "fused_cached") and of its HIP-graph
+replay ("fused_graph", "fused_cached_graph"); `--eager` adds a plain torch restatement of the reference's four
 ATen ops on the same GPU for context.  Not the driver's headline bench (that is bench.py)."""
 import argparse
 import json
@@ -55,14 +56,20 @@ def main():
     def run(kind):
         param = torch.nn.Parameter(Pbar0.clone())
         opt = torch.optim.AdamW([param], lr=1e-3, weight_decay=1e-2)
-        teacher = driver.TeacherScorer(Pt, pmt, cache_size=Qall.shape[0] if kind in ("cached", "fused_cached") else 0) if kind not in ("call_pattern", "eager") else None
+        cached = kind in ("cached", "fused_cached", "fused_cached_graph")
+        teacher = driver.TeacherScorer(Pt, pmt, cache_size=Qall.shape[0] if cached else 0) if kind not in ("call_pattern", "eager") else None
         student = driver.FusedStudent(Pbar0.clone(), pms, lr=1e-3, weight_decay=1e-2) if kind.startswith("fused") else None
+        graphed = student.graphed(B, Lq, 0.1, None if cached else teacher) if kind.endswith("_graph") else None
 
         def step(i):
             idx = torch.arange(B) + (i % 64) * B
             Qb, qmb = Qall[idx], qmall[idx]
             if kind in ("resident", "cached"):
                 return driver.train_one_step(Qb, qmb, teacher, pmt, param, pms, opt, temp=0.1, qidx=idx if kind == "cached" else None)
+            if kind == "fused_graph":                       # teacher forward + student update: one HIP-graph replay
+                return float(graphed(Qb, qmb).item())
+            if kind == "fused_cached_graph":                # teacher scores from the cache, student update replayed
+                return float(graphed(Qb, qmb, teacher.scores(Qb, qmb, idx)).item())
             if kind in ("fused", "fused_cached"):
                 return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached" else None)
             score = eager_maxsim if kind == "eager" else score_multi_vector_masked
@@ -79,7 +86,7 @@ def main():
             opt.step()
             return float(loss.item())
 
-        if kind in ("cached", "fused_cached"):
+        if cached:
             for i in range(64):
                 step(i)                                   # fill the teacher-score cache (one epoch)
         for i in range(a.warmup):
@@ -92,7 +99,7 @@ def main():
         return 1e3 * (time.perf_counter() - t0) / a.steps, last
 
     res = {}
-    kinds = ["call_pattern", "resident", "cached", "fused", "fused_cached"] + (["eager"] if a.eager else [])
+    kinds = ["call_pattern", "resident", "cached", "fused", "fused_cached", "fused_graph", "fused_cached_graph"] + (["eager"] if a.eager else [])
     if a.only:
         kinds = [k for k in kinds if k in a.only.split(",")]
     for kind in kinds:

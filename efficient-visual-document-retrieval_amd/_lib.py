@@ -29,7 +29,8 @@ SIGNATURES = {
     "evdr_maxsim_bwd_q_workspace": (_sz, [_i64, _i64]),
     "evdr_maxsim_bwd_q": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     "evdr_maxsim_bwd_adamw": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
-                                        _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
+                                        _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp, _vp]),
+    "evdr_adamw_advance": (C.c_int, [_vp, _f32, _f32, _vp]),
     "evdr_l2norm_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
     "evdr_l2norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
     "evdr_l2norm_fwd_split": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),

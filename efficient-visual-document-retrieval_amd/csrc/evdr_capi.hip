@@ -217,19 +217,25 @@ int evdr_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, cons
 int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
                           float* x, float* exp_avg, float* exp_avg_sq, int64_t nq, int64_t lq, int64_t np, int64_t lp,
                           int64_t d, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                          float l2_eps, void* hip_stream) {
+                          float l2_eps, const void* adamw_state_or_null, void* hip_stream) {
     if (int rc = check_common(nq, lq, np, lp)) return rc;
     if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported", (long long)d);
-    if (step < 1) return fail(EVDR_ERR_ARG, "step must be >= 1 (1 for the first update)");
+    if (!adamw_state_or_null && step < 1) return fail(EVDR_ERR_ARG, "step must be >= 1 (1 for the first update)");
     if (np == 0 || lp == 0) return EVDR_OK;
     if (!x || !exp_avg || !exp_avg_sq) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_adamw: null parameter/state");
     if (nq > 0 && lq > 0 && (!g || !Q || !argmax)) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_adamw: null g/Q/argmax");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow((double)beta1, (double)(step < 1 ? 1 : step));
+    const double bc2 = 1.0 - pow((double)beta2, (double)(step < 1 ? 1 : step));
     hipError_t e = evdr_launch_maxsim_bwd_adamw(g, Q, qmask, pmask, argmax, x, exp_avg, exp_avg_sq, nq, lq, np, lp, lr, beta1,
                                                 beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), l2_eps,
-                                                (hipStream_t)hip_stream);
+                                                adamw_state_or_null, (hipStream_t)hip_stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd_adamw launch");
+}
+
+int evdr_adamw_advance(void* adamw_state, float beta1, float beta2, void* hip_stream) {
+    if (!adamw_state) return fail(EVDR_ERR_ARG, "evdr_adamw_advance: null state");
+    hipError_t e = evdr_launch_adamw_advance(adamw_state, beta1, beta2, (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "adamw_advance launch");
 }
 
 int evdr_l2norm_fwd(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps, float* y,

@@ -103,7 +103,9 @@ hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t*
 hipError_t evdr_launch_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                         const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq, int64_t nq,
                                         int64_t lq, int64_t np, int64_t lp, float lr, float beta1, float beta2, float eps,
-                                        float weight_decay, float bc1, float bc2_sqrt, float eps_norm, hipStream_t stream);
+                                        float weight_decay, float bc1, float bc2_sqrt, float eps_norm, const void* state,
+                                        hipStream_t stream);
+hipError_t evdr_launch_adamw_advance(void* state, float beta1, float beta2, hipStream_t stream);
 hipError_t evdr_launch_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint32_t* pageflags,
                                     const uint16_t* argmax, float* dQ, int64_t nq, int64_t lq, int64_t np, int64_t lp,
                                     hipStream_t stream);

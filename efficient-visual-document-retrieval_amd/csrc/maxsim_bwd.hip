@@ -28,7 +28,19 @@ struct AdamArgs {
     float* exp_avg;      // first moment
     float* exp_avg_sq;   // second moment
     float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, eps_norm;
+    const float* bc_dev; // null, or {bc1, bc2_sqrt} in device memory (step counted on the device: HIP-graph replays)
 };
+
+// Device-resident step counter of an AdamW state: {int64 step; float bc1 = 1 - beta1^step; float bc2_sqrt}.  One thread; part
+// of the captured graph of a training step, so a replay needs no scalar from the host.
+__global__ void adamw_advance_kernel(void* state, float beta1, float beta2) {
+    long long* step = reinterpret_cast<long long*>(state);
+    float* bc = reinterpret_cast<float*>(step + 1);
+    const long long t = *step + 1;
+    *step = t;
+    bc[0] = (float)(1.0 - pow((double)beta1, (double)t));
+    bc[1] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+}
 
 template <int BW_ROWS, int CHUNK, bool FUSED>
 __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __restrict__ g,
@@ -165,7 +177,9 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
             f32x4 ea0 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off), ea1 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off + 4);
             f32x4 es0 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off), es1 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off + 4);
             const float decay = 1.f - ad.lr * ad.weight_decay;
-            const float step_size = ad.lr / ad.bc1;
+            const float bc1 = ad.bc_dev ? ad.bc_dev[0] : ad.bc1;
+            const float bc2_sqrt = ad.bc_dev ? ad.bc_dev[1] : ad.bc2_sqrt;
+            const float step_size = ad.lr / bc1;
             x0 *= decay;
             x1 *= decay;
             ea0 = ea0 * ad.beta1 + d0 * (1.f - ad.beta1);
@@ -174,8 +188,8 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
             es1 = es1 * ad.beta2 + d1 * d1 * (1.f - ad.beta2);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                x0[k] -= step_size * (ea0[k] / (sqrtf(es0[k]) / ad.bc2_sqrt + ad.eps));
-                x1[k] -= step_size * (ea1[k] / (sqrtf(es1[k]) / ad.bc2_sqrt + ad.eps));
+                x0[k] -= step_size * (ea0[k] / (sqrtf(es0[k]) / bc2_sqrt + ad.eps));
+                x1[k] -= step_size * (ea1[k] / (sqrtf(es1[k]) / bc2_sqrt + ad.eps));
             }
             *reinterpret_cast<f32x4*>(ad.x + off) = x0;
             *reinterpret_cast<f32x4*>(ad.x + off + 4) = x1;
@@ -410,9 +424,16 @@ hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t*
 hipError_t evdr_launch_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                         const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq, int64_t nq,
                                         int64_t lq, int64_t np, int64_t lp, float lr, float beta1, float beta2, float eps,
-                                        float weight_decay, float bc1, float bc2_sqrt, float eps_norm, hipStream_t stream) {
-    AdamArgs ad{x, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, eps_norm};
+                                        float weight_decay, float bc1, float bc2_sqrt, float eps_norm, const void* state,
+                                        hipStream_t stream) {
+    AdamArgs ad{x, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, eps_norm,
+                state ? reinterpret_cast<const float*>(reinterpret_cast<const long long*>(state) + 1) : nullptr};
     return dispatch_bwd<true>(g, Q, qmask, pmask, argmax, nullptr, nq, lq, np, lp, ad, stream);
+}
+
+hipError_t evdr_launch_adamw_advance(void* state, float beta1, float beta2, hipStream_t stream) {
+    hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, stream, state, beta1, beta2);
+    return hipGetLastError();
 }
 
 hipError_t evdr_launch_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint32_t* pageflags,

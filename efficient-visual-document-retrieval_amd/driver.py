@@ -313,8 +313,9 @@ class FusedStudent:
     def normalized(self) -> torch.Tensor:
         return ops.l2norm_forward(self.x, self.pmask, self.l2_eps)[0]
 
-    def update(self, Qb, qmb, sc_t, temp: float) -> torch.Tensor:
-        """One step given the teacher scores; returns the loss as a device scalar (no host sync)."""
+    def update(self, Qb, qmb, sc_t, temp: float, state: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One step given the teacher scores; returns the loss as a device scalar (no host sync).  With `state` (a
+        device-side step counter, ops.adamw_state) nothing in the step depends on a host scalar: graph-capturable."""
         # l2_normalize(Pbar * pmask) lands directly in the scorer's fp16 hi/lo planes (no fp32 copy, no absmax/split pass)
         pplanes, pamax = ops.l2norm_split(self.x, self.pmask, self.l2_eps)
         qplanes, qamax = ops.split_f32(Qb)
@@ -322,9 +323,66 @@ class FusedStudent:
                                                 want_argmax=True)
         loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True)
         self.steps += 1
+        if state is not None:
+            ops.adamw_advance(state, self.betas)
         ops.maxsim_backward_adamw(dscore, Qb, qmb, self.pmask, arg, self.x, self.exp_avg, self.exp_avg_sq, self.lr,
-                                  self.betas, self.eps, self.weight_decay, self.steps, self.l2_eps)
+                                  self.betas, self.eps, self.weight_decay, self.steps, self.l2_eps, state=state)
         return loss
+
+    def graphed(self, batch: int, lq: int, temp: float, teacher: Optional["TeacherScorer"] = None) -> "GraphedStep":
+        """The whole step captured ONCE in a HIP graph (torch.cuda.CUDAGraph): ~15 launches replayed with one call.
+        With `teacher`, its forward is part of the graph; without, the caller supplies the teacher scores per step
+        (e.g. from a TeacherScorer cache)."""
+        return GraphedStep(self, batch, lq, temp, teacher)
+
+
+class GraphedStep:
+    """HIP-graph replay of FusedStudent.update for a fixed batch shape.  Inputs are copied into static device buffers,
+    the AdamW step counter lives on the device (evdr_adamw_advance), the loss comes back as a device scalar."""
+
+    def __init__(self, student: FusedStudent, batch: int, lq: int, temp: float, teacher: Optional[TeacherScorer]):
+        dev = student.x.device
+        self.student, self.teacher = student, teacher
+        n = student.x.shape[0]
+        self.Qb = torch.zeros((batch, lq, ops.D), dtype=torch.float32, device=dev)
+        self.Qb[..., 0] = 1.0                                        # unit-norm rows for the warm-up passes
+        self.qmb = torch.ones((batch, lq), dtype=torch.bool, device=dev)
+        self.sc_t = torch.zeros((batch, n), dtype=torch.float32, device=dev)
+        self.state = ops.adamw_state(dev)
+
+        def body():
+            sc_t = self.sc_t if teacher is None else teacher.corpus.score(self.Qb, self.qmb)
+            return student.update(self.Qb, self.qmb, sc_t, temp, state=self.state)
+
+        # warm-up on a side stream (lazy kernel attributes, allocator pools), then restore the parameters it touched
+        keep = [t.clone() for t in (student.x, student.exp_avg, student.exp_avg_sq)]
+        steps0 = student.steps
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = body()
+        for t, k in zip((student.x, student.exp_avg, student.exp_avg_sq), keep):
+            t.copy_(k)
+        student.steps = steps0
+        self.state.zero_()
+        if steps0:                                                   # resume: the device counter continues from steps0
+            self.state[0] = steps0
+
+    def __call__(self, Qb: torch.Tensor, qmb: torch.Tensor, sc_t: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self.Qb.copy_(Qb, non_blocking=True)
+        self.qmb.copy_(qmb, non_blocking=True)
+        if self.teacher is None:
+            if sc_t is None:
+                raise RuntimeError("this graph was captured without a teacher: pass the teacher scores")
+            self.sc_t.copy_(sc_t, non_blocking=True)
+        self.graph.replay()
+        self.student.steps += 1
+        return self.loss
 
 
 def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStudent, temp: float,

@@ -256,8 +256,10 @@ def l2norm_backward(gy: torch.Tensor, x: torch.Tensor, rowmask: Optional[torch.T
 def maxsim_backward_adamw(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],
                           argmax: torch.Tensor, x: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
                           lr: float, betas: Tuple[float, float], eps: float, weight_decay: float, step: int,
-                          l2_eps: float = 1e-12) -> None:
-    """A6 + normalise/mask backward + AdamW in one launch, in place on x / exp_avg / exp_avg_sq (fp32, contiguous)."""
+                          l2_eps: float = 1e-12, state: Optional[torch.Tensor] = None) -> None:
+    """A6 + normalise/mask backward + AdamW in one launch, in place on x / exp_avg / exp_avg_sq (fp32, contiguous).
+    `state` (see `adamw_state` / `adamw_advance`): bias corrections come from the device-side step counter instead of
+    `step` -- what a HIP-graph replay of the step needs."""
     dev = _require_cuda(g, Q, argmax, x, exp_avg, exp_avg_sq)
     for t in (x, exp_avg, exp_avg_sq):
         if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != x.shape:
@@ -271,10 +273,23 @@ def maxsim_backward_adamw(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torc
     with torch.cuda.device(dev):
         L.check(lib.evdr_maxsim_bwd_adamw(L.ptr(gc), L.ptr(Qc), L.ptr(qm), L.ptr(pm), L.ptr(argmax), L.ptr(x), L.ptr(exp_avg),
                                           L.ptr(exp_avg_sq), nq, lq, npg, lp, d, float(lr), float(betas[0]), float(betas[1]),
-                                          float(eps), float(weight_decay), int(step), float(l2_eps),
+                                          float(eps), float(weight_decay), int(step), float(l2_eps), L.ptr(state),
                                           L.current_stream_handle(dev)))
     for t in (x, exp_avg, exp_avg_sq):            # written through raw pointers: tell autograd (and version-keyed caches)
         torch.autograd.graph.increment_version(t)
+
+
+def adamw_state(dev) -> torch.Tensor:
+    """Zeroed device-side AdamW step counter {int64 step; float bc1; float bc2_sqrt} (16 bytes)."""
+    return torch.zeros(2, dtype=torch.int64, device=dev)
+
+
+def adamw_advance(state: torch.Tensor, betas: Tuple[float, float]) -> None:
+    """step += 1 and refresh the bias corrections, on the device, on the current stream."""
+    dev = _require_cuda(state)
+    lib = L.load()
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_adamw_advance(L.ptr(state), float(betas[0]), float(betas[1]), L.current_stream_handle(dev)))
 
 
 def maxsim_backward_q(g: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],

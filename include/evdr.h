@@ -120,7 +120,12 @@ int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, 
                           const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq,
                           int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d,
                           float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                          float l2_eps, void* hip_stream);
+                          float l2_eps, const void* adamw_state_or_null, void* hip_stream);
+/* Device-resident step counter for the call above, so that a whole training step can be captured in a HIP graph and
+ * replayed without a scalar from the host: adamw_state = 16 bytes of device memory {int64 step; float bc1; float bc2_sqrt},
+ * zero-initialised.  evdr_adamw_advance does step += 1 and refreshes the bias corrections; evdr_maxsim_bwd_adamw with a
+ * non-NULL state reads them from there and ignores its `step` argument. */
+int evdr_adamw_advance(void* adamw_state, float beta1, float beta2, void* hip_stream);
 
 /* ---- A4: l2_normalize (utils/preprocess_data.py:8-9) fused with the page mask, forward and backward -----------------
  * y[r,:] = m_r * x[r,:] / (||m_r * x[r,:]||_2 + eps), m_r = rowmask[r] != 0 (NULL = all ones); rows x 128 fp32.

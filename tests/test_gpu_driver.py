@@ -163,3 +163,34 @@ def test_fused_student_step_matches_golden_and_torch_adamw(golden):
     fused_losses = [loss1] + [driver.fused_train_one_step(Qb, qmb, teacher, student, hp["temp"]) for _ in range(4)]
     np.testing.assert_allclose(fused_losses, ref_losses, rtol=2e-5)
     np.testing.assert_allclose(student.x.cpu().numpy(), param.detach().cpu().numpy(), atol=5e-6)
+
+
+@pytest.mark.parametrize("with_teacher", [True, False])
+def test_graphed_step_equals_eager_fused_step(golden, with_teacher):
+    """FusedStudent.graphed: the step captured once in a HIP graph and replayed == the eager fused step, over several
+    updates (device-side AdamW step counter, static input buffers); first update also against the reference fixture."""
+    import evdr_amd  # noqa: F401
+    import golden_recipes as R
+    from evdr_amd import driver
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    dev = torch.device("cuda:0")
+    z = golden("a7_step_b4n8")
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = R.train_case("b4n8")
+    Ptn = l2_normalize(Pt * pmt.unsqueeze(-1))
+    teacher = driver.TeacherScorer(Ptn.to(dev), pmt.to(dev))
+    eager = driver.FusedStudent(Pbar0.to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+    student = driver.FusedStudent(Pbar0.to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+    step = student.graphed(Qb.shape[0], Qb.shape[1], hp["temp"], teacher if with_teacher else None)
+    assert student.steps == 0 and torch.equal(student.x, eager.x)          # the capture left the parameters untouched
+    gen = torch.Generator().manual_seed(9)
+    for i in range(4):
+        Qi = Qb if i == 0 else torch.nn.functional.normalize(torch.randn(Qb.shape, generator=gen), dim=-1)
+        sc_t = teacher.scores(Qi.to(dev), qmb.to(dev))
+        le = float(eager.update(Qi.to(dev), qmb.to(dev), sc_t, hp["temp"]).item())
+        lg = float((step(Qi, qmb) if with_teacher else step(Qi, qmb, sc_t)).item())
+        np.testing.assert_allclose(lg, le, rtol=1e-6)
+        if i == 0:
+            np.testing.assert_allclose(lg, float(z["loss"]), rtol=1e-5)
+            np.testing.assert_allclose(student.x.cpu().numpy(), z["param_after"], atol=1e-6)
+        np.testing.assert_allclose(student.x.cpu().numpy(), eager.x.cpu().numpy(), atol=2e-6)
+    assert student.steps == eager.steps == 4 and int(step.state[0].item()) == 4
