@@ -53,7 +53,7 @@ struct EvdrFwdParams {
 // of `ppb` pages each plus a fixed cost per workgroup (query load + ring fill, worth about 16 tiles of MFMA work).
 // Pick the ppb in [lo, 64] that minimises rounds x (ppb + fixed): this avoids e.g. 1539 workgroups = 6 full rounds + a
 // seventh for 3 workgroups.  lo: a workgroup should stream >= ~64 tiles, otherwise the fixed cost dominates -- unless
-// that would leave CUs without any workgroup.  Many rounds (>= 24) need no tuning: take <= 64 pages, ~6+ rounds.
+// that would leave CUs without any workgroup.  Many rounds (>= 64) need no tuning: take 64 pages.
 static inline int evdr_pages_per_block(int64_t np, int64_t n_qgroups, int64_t ntiles) {
     const int64_t total = np * n_qgroups;
     int64_t lo = (64 + ntiles - 1) / ntiles;
@@ -65,7 +65,7 @@ static inline int evdr_pages_per_block(int64_t np, int64_t n_qgroups, int64_t nt
     if (hi < lo) hi = lo;
     if (hi > np) hi = np;
     if (lo > hi) lo = hi;
-    if (total / (256 * hi) >= 24) return (int)hi;        // tail round <= 4 % whatever the choice
+    if (total / (256 * hi) >= 64) return (int)hi;        // tail round <= 1.5 % whatever the choice
     int64_t best = hi;
     double best_cost = 1e30;
     for (int64_t ppb = np < 64 ? np : 64; ppb >= lo; --ppb) {
