@@ -48,6 +48,8 @@ class EvdrError(RuntimeError):
         self.code = code
 
 
+ABI_VERSION = 200                  # EVDR_VERSION_NUM of csrc/evdr_common.h these signatures belong to
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -61,6 +63,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import "
             f"__graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback for this path.")
     lib = C.CDLL(LIB_PATH)
+    lib.evdr_version.restype = C.c_int
+    if lib.evdr_version() != ABI_VERSION:      # a stale build would be called with the wrong argument lists
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.evdr_version()}, these bindings are written for {ABI_VERSION}: "
+                           f"rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header / library out of sync
         fn.restype = res

@@ -29,7 +29,6 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
     // EVDR_FWD_VARIANT is an experiment switch read per launch (0/unset = default; see evdr_launch_maxsim_fwd16)
     const char* e = getenv("EVDR_FWD_VARIANT");
     const int variant = e ? atoi(e) : 0;
-    if (variant == 5) qw = 1;                              // A/B: one query per wave
     // HBM-bound launches (a handful of queries) want the refill in flight as early as possible: +3 % at 1-4 queries;
     // everything else hides the refill's address work under MFMAs: +2..4 %
     p.inblock_refill = p.nq > 4 ? 1 : 0;

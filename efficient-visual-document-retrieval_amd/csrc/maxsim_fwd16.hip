@@ -730,9 +730,9 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
 
 // NPL = 1 without argmax (retrieval / eval): geom 0 (default) = page-aligned 8-tile stages with the self-balancing priority
 // schedule (maxsim_fwd16s_kernel) for pages of >= 8 tiles, the flat per-tile ring (maxsim_fwd16_kernel) for shorter
-// pages; geom 1 forces the flat kernel, geom 2 the staged kernel without the priority schedule, 3 a deeper flat ring,
-// 4 two workgroups per CU (A/B experiments); 50/51 are the stamped diagnostic builds.
-// Argmax and fp16 hi/lo planes (nplanes = 2): the staged kernel for every page length.
+// pages; geom 1 forces the flat kernel, geom 2 the staged kernel without the priority schedule (A/B experiments);
+// 50/51 are the stamped diagnostic builds.  Argmax and fp16 hi/lo planes (nplanes = 2): the staged kernel for every
+// page length.
 hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes, bool want_argmax, int geom, hipStream_t stream) {
     const int ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     if (nplanes == 2) {                                  // 4-tile stages of 16-KiB tiles: 2 x 5 x 16 KiB = all 160 KiB of LDS
@@ -747,16 +747,10 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes,
         return geom == 50 ? launch16s<4, 1, false, 8, 2, true, false>(pd, stream) : launch16s<4, 1, false, 8, 2, true, true>(pd, stream);
     }
     if (geom == 2 && ntiles >= 8 && qw == 4) return launch16s<4, 1, false, 8, 2, false, false>(p, stream);   // A/B: no priority schedule
-    if (geom == 4 && ntiles >= 8 && qw == 1) return launch16s<1, 1, false, 4, 2, false, false, 4>(p, stream);  // A/B: 2 WGs per CU
-    if ((geom != 1 && geom != 3 && geom != 4 && ntiles >= 8) || p.per_token) {
+    if ((geom != 1 && ntiles >= 8) || p.per_token) {
         if (qw == 4) return launch16s<4, 1, false, 8, 2, false, true>(p, stream);
         if (qw == 2) return launch16s<2, 1, false, 8, 2, false, true>(p, stream);
         return launch16s<1, 1, false, 8, 2, false, true>(p, stream);
-    }
-    if (geom == 3) {                                    // A/B: deeper flat ring (3 of 4 stages in flight)
-        if (qw == 4) return launch16<4, 8, 4, 4>(p, stream);
-        if (qw == 2) return launch16<2, 8, 4, 4>(p, stream);
-        return launch16<1, 8, 4, 4>(p, stream);
     }
     if (qw == 4) return launch16<4, 8, 4, 3>(p, stream);
     if (qw == 2) return launch16<2, 8, 4, 3>(p, stream);
