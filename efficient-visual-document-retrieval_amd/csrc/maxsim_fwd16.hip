@@ -1,11 +1,10 @@
 // MaxSim forward on the 16x16x32 MFMA shape: bf16 inputs (retrieval hot path) and fp32 inputs as fp16 hi/lo planes.
 //
-// Same structure as maxsim_fwd.hip (queries resident as the MFMA B operand, token on the lane, LDS-DMA ring,
-// XOR-swizzled conflict-free A reads, XCD-aware block map, fast path for all-valid tiles).  Why a second
-// shape: under MFMA-dense load on random data MI355X lowers its clock, and the clock it holds depends on the
-// MFMA shape (MI355X_MICROARCH.md "DVFS give-back" item 7: the 16x16x32 loop delivers more FLOP/s than the
-// 32x32x16 loop at equal cycles per FLOP).  The 16-patch granularity also trims the tail of a 1030-patch page
-// (65 x 16 = 1040 rows instead of 33 x 32 = 1056).
+// Mapping: see the header of maxsim_fwd.hip (queries resident as the MFMA B operand, token on the lane, LDS-DMA ring,
+// XOR-swizzled conflict-free A reads, XCD-aware block map, fast path for all-valid tiles).  Why this shape: under
+// MFMA-dense load on real data MI355X is power-limited, and a register-only MFMA loop sustains 1.90 PFLOP/s with
+// 16x16x32 against 1.81 with 32x32x16 (scratch/probe/mfma_peak.hip).  The 16-patch granularity also trims the tail of
+// a 1030-patch page (65 x 16 = 1040 rows instead of 33 x 32 = 1056).
 //
 // Fragment maps (cdna_hip_programming.md §3), lane l: c = l & 15, g = l >> 4
 //   A[row c][k = 8g + j]   = patch (16u + c) of the tile, dims 32s + 8g + j      (u = 16-patch half, s = k-step)
