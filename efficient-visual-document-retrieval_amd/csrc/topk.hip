@@ -2,15 +2,20 @@
 // Nq*N `.item()` loop that moves every score to the host before ranking
 // (mainv2_iter_distill_infonce.py:311-317); k = 100 covers every cut-off in evaluator/retrieval.py:223.
 //
-// One 256-thread workgroup per row: 4 x 8-bit radix-select passes find the k-th largest key exactly,
-// one pass gathers the candidates, a 128-wide bitonic sort orders them.  Order is total and
+// One 256-thread workgroup per row: 3 radix-select passes (11 + 11 + 10 bits, LDS histogram of 2048 bins) find the k-th
+// largest key exactly, one pass gathers the candidates, a 128-wide bitonic sort orders them.  Order is total and
 // deterministic: score descending, reported index ascending on ties (the shard merge relies on it).
 // HBM-bound integer work: the row is read once from HBM, the re-reads hit L2 (400 KB per 100k-page row).
+// The first digit (sign, exponent, two mantissa bits) is the same for almost every score of a row, and 64 LDS atomics on
+// one address serialise: that pass counts per WAVE (ballot + popcount, one atomic per distinct digit), the others use
+// plain atomics on digits that spread over the bins.
 #include "evdr_common.h"
 
 namespace {
 
 constexpr int TK_THREADS = 256;
+constexpr int TK_BINS = 2048;
+constexpr int TK_BPT = TK_BINS / TK_THREADS;     // histogram bins per thread in the suffix scan
 
 __device__ __forceinline__ uint32_t order_key(float f) {
     f = f + 0.0f;                                    // -0.0 -> +0.0 so that equal scores tie
@@ -27,7 +32,7 @@ __global__ void __launch_bounds__(TK_THREADS) topk_kernel(const float* __restric
                                                          int64_t row_stride, int32_t idx_base, int k,
                                                          float* __restrict__ top_scores,
                                                          int32_t* __restrict__ top_idx) {
-    __shared__ uint32_t hist[TK_THREADS];
+    __shared__ uint32_t hist[TK_BINS];
     __shared__ uint32_t suf[TK_THREADS + 1];
     __shared__ unsigned long long cand[EVDR_TOPK_MAX];
     __shared__ uint32_t sh_prefix, sh_need, sh_cnt_eq, sh_cnt_gt_slot, sh_eq_slot, sh_wave_tot[TK_THREADS / 64];
@@ -38,26 +43,88 @@ __global__ void __launch_bounds__(TK_THREADS) topk_kernel(const float* __restric
     const float* row = scores + rowi * row_stride;
     const int32_t* map = idx_map ? idx_map + rowi * n : nullptr;
     const int keff = (int)min((int64_t)k, n);
+    // Row scan with 16-B loads, 16-32 elements in flight per thread (one workgroup has to keep enough bytes in flight to cover the
+    // L2 latency: scalar loads left it at ~4 GB/s per row).  body(valid, key, index) is called the same number of times by
+    // every thread, so it may use wave-level votes.
+    const int mis = (int)((reinterpret_cast<uintptr_t>(row) >> 2) & 3);            // floats past a 16-B boundary
+    const int head = (int)min((int64_t)((4 - mis) & 3), n);
+    const int64_t nvec = (n - head) / 4;
+    const int tail = (int)(n - head - 4 * nvec);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(row + head);
+    auto scan = [&](auto&& body) {
+        {
+            int64_t i = -1;
+            if (tid < head) i = tid;
+            else if (tid < head + tail) i = n - tail + (tid - head);
+            const bool v = i >= 0;
+            body(v, v ? order_key(row[i]) : 0u, i);
+        }
+        // software-pipelined: the loads of the next round are in flight while this round's keys are counted
+        constexpr int U = 4;
+        f32x4 cur[U], nxt[U];
+        auto fetch = [&](f32x4 (&x)[U], int64_t v0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t j = v0 + u * TK_THREADS + tid;
+                x[u] = (j < nvec) ? r4[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        fetch(cur, 0);
+        for (int64_t v0 = 0; v0 < nvec; v0 += U * TK_THREADS) {
+            if (v0 + U * TK_THREADS < nvec) fetch(nxt, v0 + U * TK_THREADS);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t j = v0 + u * TK_THREADS + tid;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float f = cur[u][e];
+                    body(j < nvec, order_key(f), head + 4 * j + e);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+    };
 
     if (tid < EVDR_TOPK_MAX) cand[tid] = 0ull;       // key 0 sorts below every real score
     if (tid == 0) { sh_prefix = 0; sh_need = (uint32_t)keff; sh_cnt_gt_slot = 0; sh_eq_slot = 0; sh_eq_base = 0; }
     __syncthreads();
 
     if (keff > 0) {
-        // ---- radix select, most significant byte first
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            hist[tid] = 0;
+        // ---- radix select, most significant digit first
+        const int lane = tid & 63;
+        for (int pass = 0; pass < 3; ++pass) {
+            const int shift = (pass == 0) ? 21 : (pass == 1 ? 10 : 0);
+            const int bits = (pass == 2) ? 10 : 11;
+            const uint32_t dmask = (1u << bits) - 1u;
+#pragma unroll
+            for (int b = 0; b < TK_BPT; ++b) hist[tid * TK_BPT + b] = 0;
             __syncthreads();
             const uint32_t prefix = sh_prefix;
-            const uint32_t himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
-            for (int64_t i = tid; i < n; i += TK_THREADS) {
-                const uint32_t key = order_key(row[i]);
-                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-            }
+            const uint32_t himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + bits));
+            scan([&](bool valid, uint32_t key, int64_t) {
+                const uint32_t d = (key >> shift) & dmask;
+                bool mine = valid && ((key & himask) == prefix);
+                if (pass == 0) {
+                    // wave-level counting of the (few) distinct digits; whatever is left after 3 rounds goes one by one
+                    unsigned long long todo = __ballot(mine);
+                    for (int it = 0; it < 3 && todo != 0ull; ++it) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+                        const unsigned long long same = __ballot(mine && d == dl);
+                        if (lane == leader) atomicAdd(&hist[dl], (uint32_t)__popcll(same));
+                        todo &= ~same;
+                        mine = mine && d != dl;
+                    }
+                }
+                if (mine) atomicAdd(&hist[d], 1u);
+            });
             __syncthreads();
-            // suffix sums: suf[t] = sum_{b >= t} hist[b]
-            suf[tid] = hist[tid];
+            // suffix sums over the bins, TK_BPT bins per thread: suf[t] = count of digits >= TK_BPT * t
+            uint32_t own = 0;
+#pragma unroll
+            for (int b = 0; b < TK_BPT; ++b) own += hist[tid * TK_BPT + b];
+            suf[tid] = own;
             if (tid == 0) suf[TK_THREADS] = 0;
             __syncthreads();
             for (int off = 1; off < TK_THREADS; off <<= 1) {
@@ -67,10 +134,18 @@ __global__ void __launch_bounds__(TK_THREADS) topk_kernel(const float* __restric
                 __syncthreads();
             }
             const uint32_t need = sh_need;
-            if (suf[tid] >= need && suf[tid + 1] < need) {      // exactly one thread
-                sh_prefix = prefix | ((uint32_t)tid << shift);
-                sh_need = need - suf[tid + 1];
-                sh_cnt_eq = hist[tid];
+            if (suf[tid] >= need && suf[tid + 1] < need) {      // exactly one thread: the wanted digit is one of its bins
+                uint32_t above = suf[tid + 1];
+                for (int b = TK_BPT - 1; b >= 0; --b) {
+                    const uint32_t cnt = hist[tid * TK_BPT + b];
+                    if (above + cnt >= need) {
+                        sh_prefix = prefix | ((uint32_t)(tid * TK_BPT + b) << shift);
+                        sh_need = need - above;
+                        sh_cnt_eq = cnt;
+                        break;
+                    }
+                    above += cnt;
+                }
             }
             __syncthreads();
         }
@@ -80,19 +155,18 @@ __global__ void __launch_bounds__(TK_THREADS) topk_kernel(const float* __restric
         const bool take_all_eq = (sh_cnt_eq == need_eq);
 
         // ---- gather: everything above T, plus (all | the first need_eq in index order) of == T
-        for (int64_t i = tid; i < n; i += TK_THREADS) {
-            const uint32_t key = order_key(row[i]);
-            const bool gt = key > T;
-            const bool eq = take_all_eq && key == T;
+        scan([&](bool valid, uint32_t key, int64_t i) {
+            const bool gt = valid && key > T;
+            const bool eq = valid && take_all_eq && key == T;
             if (gt || eq) {
                 const uint32_t slot = gt ? atomicAdd(&sh_cnt_gt_slot, 1u) : n_gt + atomicAdd(&sh_eq_slot, 1u);
                 const uint32_t rep = (uint32_t)(map ? map[i] : (int32_t)i + idx_base);
                 cand[slot] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - rep);
             }
-        }
+        });
         if (!take_all_eq) {
             // the tie straddles the cut: ordered scan, stop once need_eq have been taken
-            const int lane = tid & 63, wv = tid >> 6;
+            const int wv = tid >> 6;
             for (int64_t base = 0; base < n; base += TK_THREADS) {
                 const int64_t i = base + tid;
                 const bool eq = (i < n) && order_key(row[i]) == T;
