@@ -313,20 +313,28 @@ class FusedStudent:
     def normalized(self) -> torch.Tensor:
         return ops.l2norm_forward(self.x, self.pmask, self.l2_eps)[0]
 
-    def update(self, Qb, qmb, sc_t, temp: float, state: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """One step given the teacher scores; returns the loss as a device scalar (no host sync).  With `state` (a
-        device-side step counter, ops.adamw_state) nothing in the step depends on a host scalar: graph-capturable."""
-        # l2_normalize(Pbar * pmask) lands directly in the scorer's fp16 hi/lo planes (no fp32 copy, no absmax/split pass)
+    def scores(self, Qb, qmb) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Student scores (B, n_pages) and the argmax the update needs.  l2_normalize(Pbar * pmask) lands directly in the
+        scorer's fp16 hi/lo planes (no fp32 copy, no absmax/split pass)."""
         pplanes, pamax = ops.l2norm_split(self.x, self.pmask, self.l2_eps)
         qplanes, qamax = ops.split_f32(Qb)
-        sc_s, arg = ops.maxsim_forward_prepared(qplanes, qamax, pplanes, pamax, qmb, self.tilemask, self.pageflags,
-                                                want_argmax=True)
-        loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True)
+        return ops.maxsim_forward_prepared(qplanes, qamax, pplanes, pamax, qmb, self.tilemask, self.pageflags,
+                                           want_argmax=True)
+
+    def apply(self, dscore, Qb, qmb, arg, state: Optional[torch.Tensor] = None) -> None:
+        """Backward gather -> normalise backward -> AdamW, one kernel, given d(loss)/d(scores) of THIS student's pages."""
         self.steps += 1
         if state is not None:
             ops.adamw_advance(state, self.betas)
         ops.maxsim_backward_adamw(dscore, Qb, qmb, self.pmask, arg, self.x, self.exp_avg, self.exp_avg_sq, self.lr,
                                   self.betas, self.eps, self.weight_decay, self.steps, self.l2_eps, state=state)
+
+    def update(self, Qb, qmb, sc_t, temp: float, state: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One step given the teacher scores; returns the loss as a device scalar (no host sync).  With `state` (a
+        device-side step counter, ops.adamw_state) nothing in the step depends on a host scalar: graph-capturable."""
+        sc_s, arg = self.scores(Qb, qmb)
+        loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True)
+        self.apply(dscore, Qb, qmb, arg, state)
         return loss
 
     def graphed(self, batch: int, lq: int, temp: float, teacher: Optional["TeacherScorer"] = None) -> "GraphedStep":
@@ -396,10 +404,29 @@ def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStuden
 # ----------------------------------------------------------------------------------------------------
 # Page-sharded training step (SURVEY §8(e) "Training partitioning"; no counterpart in the reference)
 # ----------------------------------------------------------------------------------------------------
+def gather_columns(block: torch.Tensor, sizes, group=None) -> torch.Tensor:
+    """(B, n_local) score block of this rank -> full (B, N) rows on every rank: ONE all-gather of equal-sized messages
+    (B * max(sizes) floats per rank; 8 KB at B = 32, N = 500, 8 ranks).  nccl = RCCL over xGMI with device tensors;
+    gloo (CPU rehearsal of the exchange) goes through host memory."""
+    import torch.distributed as dist
+    b = block.shape[0]
+    nmax = max(sizes)
+    msg = torch.zeros((b, nmax), dtype=torch.float32, device=block.device)
+    msg[:, : block.shape[1]] = block
+    if dist.get_backend(group) == "gloo" and msg.is_cuda:
+        buf = torch.empty((len(sizes) * b, nmax), dtype=torch.float32)
+        dist.all_gather_into_tensor(buf, msg.cpu(), group=group)
+        buf = buf.to(block.device)
+    else:
+        buf = torch.empty((len(sizes) * b, nmax), dtype=torch.float32, device=block.device)
+        dist.all_gather_into_tensor(buf, msg, group=group)
+    buf = buf.view(len(sizes), b, nmax)
+    return torch.cat([buf[r, :, : sizes[r]] for r in range(len(sizes))], dim=1)
+
+
 class _GatherColumns(torch.autograd.Function):
-    """(B, n_local) score block of this rank -> full (B, N) rows on every rank (all-gather over the page shards);
-    the backward keeps this rank's own columns of the upstream gradient: the parameters are sharded, not
-    replicated, so there is NO gradient all-reduce."""
+    """gather_columns with autograd: the backward keeps this rank's own columns of the upstream gradient -- the
+    parameters are sharded, not replicated, so there is NO gradient all-reduce."""
 
     @staticmethod
     def forward(ctx, block, sizes, group):
@@ -407,25 +434,30 @@ class _GatherColumns(torch.autograd.Function):
         rank = dist.get_rank(group)
         ctx.lo = int(sum(sizes[:rank]))
         ctx.n_local = int(sizes[rank])
-        backend = dist.get_backend(group)
-        b = block.shape[0]
-        nmax = max(sizes)
-        msg = torch.zeros((b, nmax), dtype=torch.float32, device=block.device)      # equal-sized messages
-        msg[:, : block.shape[1]] = block
-        if backend == "gloo" and msg.is_cuda:                                       # CPU rehearsal of the exchange
-            host = msg.cpu()
-            buf = torch.empty((len(sizes) * b, nmax), dtype=torch.float32)
-            dist.all_gather_into_tensor(buf, host, group=group)
-            buf = buf.to(block.device)
-        else:                                                                       # nccl = RCCL over xGMI
-            buf = torch.empty((len(sizes) * b, nmax), dtype=torch.float32, device=block.device)
-            dist.all_gather_into_tensor(buf, msg, group=group)
-        buf = buf.view(len(sizes), b, nmax)
-        return torch.cat([buf[r, :, : sizes[r]] for r in range(len(sizes))], dim=1)
+        return gather_columns(block, sizes, group)
 
     @staticmethod
     def backward(ctx, g):
         return g[:, ctx.lo: ctx.lo + ctx.n_local].contiguous(), None, None
+
+
+def sharded_fused_train_one_step(Qb, qmb, teacher_shard: "TeacherScorer", student_shard: FusedStudent, temp: float,
+                                 shard_sizes, group=None, qidx: Optional[torch.Tensor] = None) -> float:
+    """`sharded_train_one_step` on the fused kernels: every rank scores its page shard for teacher and student, the two
+    (B, n_local) blocks are all-gathered, the loss kernel runs redundantly on the full rows, and each rank's slice of
+    d(loss)/d(scores) drives its own backward + AdamW kernel.  No autograd graph, no gradient all-reduce."""
+    import torch.distributed as dist
+    device = student_shard.x.device
+    Qb = Qb.to(device, non_blocking=True).float()
+    qmb = qmb.to(device, non_blocking=True)
+    rank = dist.get_rank(group)
+    lo = int(sum(shard_sizes[:rank]))
+    sc_s_local, arg = student_shard.scores(Qb, qmb)
+    sc_t = gather_columns(teacher_shard.scores(Qb, qmb, qidx), tuple(shard_sizes), group)
+    sc_s = gather_columns(sc_s_local, tuple(shard_sizes), group)
+    loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True)
+    student_shard.apply(dscore[:, lo: lo + int(shard_sizes[rank])].contiguous(), Qb, qmb, arg)
+    return float(loss.item())
 
 
 def sharded_train_one_step(Qb, qmb, teacher_shard, Pbar_shard, pmask_student_shard, opt, temp: float,

@@ -39,7 +39,10 @@ def _worker(rank, world, port, ret):
         opt = torch.optim.AdamW([param], lr=hp["lr"], weight_decay=hp["wd"])
         losses = [driver.sharded_train_one_step(Qb, qmb, teacher, param, pms[lo:hi].to(dev), opt, hp["temp"], sizes)
                   for _ in range(2)]
-        ret[rank] = (losses, param.detach().cpu().numpy())
+        # the same two steps on the fused kernels (no autograd graph): FusedStudent over this rank's pages
+        student = driver.FusedStudent(Pbar0[lo:hi].to(dev), pms[lo:hi].to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+        flosses = [driver.sharded_fused_train_one_step(Qb, qmb, teacher, student, hp["temp"], sizes) for _ in range(2)]
+        ret[rank] = (losses, param.detach().cpu().numpy(), flosses, student.x.cpu().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -67,3 +70,7 @@ def test_sharded_step_equals_single_device():
         np.testing.assert_allclose(got[r][0], ref_losses, rtol=1e-6)           # same loss on every rank, both steps
     merged = np.concatenate([got[r][1] for r in range(world)], axis=0)
     np.testing.assert_allclose(merged, param.detach().cpu().numpy(), atol=1e-6)
+    for r in range(world):
+        np.testing.assert_allclose(got[r][2], ref_losses, rtol=2e-6)           # fused sharded step: same losses ...
+    fused = np.concatenate([got[r][3] for r in range(world)], axis=0)
+    np.testing.assert_allclose(fused, param.detach().cpu().numpy(), atol=2e-6)  # ... and the same parameters
