@@ -126,16 +126,17 @@ def score_multi_vector_masked(
 # A2 / A3: the ColPali-style list scorers
 # ------------------------------------------------------------------------------------------------
 def _left_pad_stack(seqs: List[torch.Tensor], device) -> torch.Tensor:
-    """Zero LEFT padding to the batch's own max length (evaluator/retrieval.py:30-45), built in one
-    device tensor instead of per-sequence torch.cat."""
+    """Zero LEFT padding to the batch's own max length (evaluator/retrieval.py:30-45), built in one tensor instead of
+    per-sequence torch.cat; host sequences are padded on the host and cross PCIe as ONE copy."""
     seqs = [s.unsqueeze(0) if s.ndim == 1 else s for s in seqs]
     lmax = max(int(s.shape[0]) for s in seqs)
     d = int(seqs[0].shape[-1])
-    out = torch.zeros((len(seqs), lmax, d), dtype=seqs[0].dtype, device=device)
+    on_host = all(not s.is_cuda for s in seqs)
+    out = torch.zeros((len(seqs), lmax, d), dtype=seqs[0].dtype, device="cpu" if on_host else device)
     for i, s in enumerate(seqs):
         if s.shape[0]:
-            out[i, lmax - s.shape[0]:] = s.to(device)
-    return out
+            out[i, lmax - s.shape[0]:] = s if on_host else s.to(device)
+    return out.to(device) if on_host else out
 
 
 class BaseVisualRetrieverProcessor(ABC):
