@@ -88,7 +88,7 @@ def host_cores() -> int:
 
 def cpu_baseline_leg(dev_corpus_slice: torch.Tensor, Qdev: torch.Tensor):
     """The reference's scorer as restated in oracle/ (torch fp32 on the host, chunk_p=64), on a bounded slice of the
-    SAME workload: 32 queries x 2048 pages.  A reported baseline, not a target."""
+    SAME workload: 32 queries x 4096 pages (about 10 s of host work).  A reported baseline, not a target."""
     from oracle import maxsim_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -125,11 +125,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC for RCCL; before the first HIP call
     dev_index = local_rank % max(torch.cuda.device_count(), 1)     # gloo rehearsal: several ranks may share a GPU
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -209,7 +209,7 @@ def main():
         res = results_from_topk(ts.cpu().numpy(), ti.cpu().numpy(), [str(i) for i in range(args.queries)], docids)
         ndcg5 = CustomRetrievalEvaluator().compute_mteb_metrics(qrels, res)["NDCG"]["NDCG@5"]
         if world == 1 and not args.no_cpu_baseline:
-            n_cpu = min(2048, corpus.n_pages)
+            n_cpu = min(4096, corpus.n_pages)
             cpu_base, s_cpu = cpu_baseline_leg(shard_pages[:n_cpu], Q)
             dmax = (out[:32, :n_cpu].cpu() - s_cpu).abs().max().item()      # same inputs: the oracle as checker
             cpu_base["max_abs_diff_vs_gpu"] = dmax
