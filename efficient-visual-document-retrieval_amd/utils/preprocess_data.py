@@ -183,7 +183,7 @@ def corpus_from_payload(documents_obj, doc_attnmask_obj, doc_imgmask_obj, device
     """Object arrays of a feature dump -> resident PageCorpus, page by page: each page is masked, L2-normalised
     (what the scripts do before scoring, mainv2_iter_distill_infonce.py:94) and stored in the corpus dtype; the
     only full-size device buffer is the final (N, Lmax, 128) one in `dtype` (bf16: half of the reference's fp32
-    padded tensor; torch.float32 keeps fp32 accuracy through the 3-plane split)."""
+    padded tensor; torch.float32 keeps fp32 accuracy through the fp16 hi/lo split)."""
     from ..corpus import PageCorpus
     docs = _as_object_array(documents_obj)
     n = len(docs)
