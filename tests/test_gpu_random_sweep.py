@@ -65,7 +65,7 @@ def test_random_argmax_and_backward(seed):
     s_o, arg_o = O.maxsim_masked_argmax(Qf, Pf, qm, pm)
     g = torch.randn(s_o.shape, generator=torch.Generator().manual_seed(seed))
     dP_o = O.maxsim_backward(g, Qf, Pf, qm, pm)
-    for Qx, Px in ((Q, P), (Qf, Pf)):                # bf16 kernel with argmax, fp32 (3-plane) kernel with argmax
+    for Qx, Px in ((Q, P), (Qf, Pf)):                # bf16 kernel with argmax, fp32 (fp16 hi/lo planes) kernel with argmax
         s, arg = ops.maxsim_forward(Qx.to(dev), Px.to(dev), qm.to(dev), pm.to(dev), want_argmax=True)
         np.testing.assert_allclose(s.cpu().numpy(), s_o.numpy(), atol=1e-4, rtol=0)
         arg = arg.cpu().to(torch.int32) & 0xFFFF
