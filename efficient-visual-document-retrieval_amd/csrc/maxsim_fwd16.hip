@@ -274,7 +274,7 @@ __device__ __forceinline__ void xgroup_argmax(float& v, int& idx) {
     }
 }
 
-template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, bool SPQ2 = false>
 __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
     using frag = typename FragOf<NPL>::type;
     constexpr int WAVES = 8;
@@ -364,9 +364,16 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
         const int row0 = (t0 + tis) * EVDR_TILE_PATCHES + piece * 4;                 // first patch row of the piece (uniform)
         const int rbase = min(row0, p.lp - 1);
         const uint16_t* sb = p.P + (int64_t)pl * p.p_plane_stride + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
-        uint32_t voff = swz[piece & 3] + lgoff;
+        uint32_t sw = swz[piece & 3], lg = lgoff;
+        if constexpr (SPQ2) {                                                        // rebuilt per piece: nothing stays live
+            uint32_t l = (uint32_t)lane;
+            asm volatile("" : "+v"(l));
+            sw = ((l & 15u) ^ ((4u * (piece & 3) + (l >> 4)) & 15u)) << 4;
+            lg = (l >> 4) * 256u;
+        }
+        uint32_t voff = sw + lg;
         if (!KNOWN_FULL && row0 + 3 >= p.lp)                                         // uniform: only a page's tail tile
-            voff = swz[piece & 3] + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
+            voff = sw + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
         lds_dma_16B_sbase(sb, voff,
                           __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + tis * TILE_B + pl * TILE_BYTES + piece * 1024));
     };
@@ -390,9 +397,11 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
         for (int i = 0; i < G; ++i) issue_piece(S, slot, i, std::false_type{});
         issue_extra(S, slot);
     };
-    // in-block refill: NPL pieces per tile of the straight-line block (not for QW = 2 on fp16 planes: the piece addressing
-    // pushes that instance over the register file, and a scratch reload inside the block would wait on the DMA queue)
-    constexpr bool SPREAD = (NSTAGE == 2) && !(NPL == 2 && QW == 2);
+    // in-block refill: NPL pieces per tile of the straight-line block.  QW = 2 on fp16 planes is at the limit of the register
+    // file: there the refill is in-block only in the SPQ2 instantiation, which rebuilds the per-lane offsets of a piece
+    // from the lane id (6 VALU per piece) instead of keeping five VGPRs live through the block (the bf16 QW = 4 instance
+    // measured 0.8 % slower that way and keeps them)
+    constexpr bool SPREAD = (NSTAGE == 2) && (SPQ2 || !(NPL == 2 && QW == 2));
 
     typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
     cptr_t tilemask_c = (cptr_t)(uintptr_t)p.tilemask;
@@ -701,11 +710,11 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
     }
 }
 
-template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, bool SPQ2 = false>
 hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
     constexpr int LDS = NSTAGE * (ST + 1) * NPL * TILE_BYTES;
-    auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC>;
+    auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC, SPQ2>;
     static uint64_t attr_devs = 0;
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, 8 * QW);
@@ -735,8 +744,14 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
 hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes, bool want_argmax, int geom, hipStream_t stream) {
     const int ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     if (nplanes == 2) {                                  // 4-tile stages of 16-KiB tiles: 2 x 5 x 16 KiB = all 160 KiB of LDS
-        if (want_argmax) return qw == 2 ? launch16s<2, 2, true, 4, 2, false, true>(p, stream) : launch16s<1, 2, true, 4, 2, false, true>(p, stream);
-        return qw == 2 ? launch16s<2, 2, false, 4, 2, false, true>(p, stream) : launch16s<1, 2, false, 4, 2, false, true>(p, stream);
+        // QW = 2: in-block refill with the lane offsets rebuilt per piece (SPQ2): +12 % on the 32 x 500 teacher forward;
+        // geom 9 = A/B without it
+        if (want_argmax) {
+            if (qw == 2) return geom == 9 ? launch16s<2, 2, true, 4, 2, false, true>(p, stream) : launch16s<2, 2, true, 4, 2, false, true, 2, true>(p, stream);
+            return launch16s<1, 2, true, 4, 2, false, true>(p, stream);
+        }
+        if (qw == 2) return geom == 9 ? launch16s<2, 2, false, 4, 2, false, true>(p, stream) : launch16s<2, 2, false, 4, 2, false, true, 2, true>(p, stream);
+        return launch16s<1, 2, false, 4, 2, false, true>(p, stream);
     }
     if (want_argmax) return qw == 2 ? launch16s<2, 1, true, 8, 2, false, true>(p, stream) : launch16s<1, 1, true, 8, 2, false, true>(p, stream);
     if ((geom == 50 || geom == 51) && ntiles >= 8 && qw == 4) {   // diagnostic builds with in-kernel stamps (scratch/diag_stamps.py)
