@@ -198,3 +198,30 @@ def test_logger_line_contract(tmp_path):
     assert re.match(r"^\[[^\]]+\]\[INFO\] \{", line)
     obj = json.loads(line[line.index("{"):])
     assert obj["summary/best_ndcg5"]["NDCG@5"] == 0.83
+
+
+def test_metrics_vs_sklearn(pkg):
+    """Independent third-party cross-check of the metric the reference takes from mteb/pytrec_eval (absent here, parity
+    unpinned): scikit-learn's ndcg_score (linear gain, log2 discount -- trec_eval's ndcg_cut) and average_precision_score
+    (trec_eval's map when the cut-off covers the whole ranking), on distinct scores with graded relevance."""
+    sk = pytest.importorskip("sklearn.metrics")
+    rng = np.random.default_rng(5)
+    nd, nq = 40, 60
+    docids = [f"doc{j}" for j in range(nd)]
+    qrels, results = {}, {}
+    want_ndcg = {k: [] for k in (1, 3, 5, 10)}
+    want_map = []
+    for i in range(nq):
+        sc = rng.permutation(nd).astype(np.float64) + rng.random(nd) * 0.1        # distinct scores: no tie rule involved
+        rel = np.zeros(nd, dtype=np.int64)
+        rel[rng.choice(nd, size=int(rng.integers(1, 6)), replace=False)] = rng.integers(1, 4, size=1)[0]
+        rel[int(rng.integers(nd))] = int(rng.integers(1, 4))
+        qrels[f"q{i}"] = {docids[j]: int(rel[j]) for j in range(nd) if rel[j] > 0}
+        results[f"q{i}"] = {docids[j]: float(sc[j]) for j in range(nd)}
+        for k in want_ndcg:
+            want_ndcg[k].append(sk.ndcg_score(rel[None, :], sc[None, :], k=k))
+        want_map.append(sk.average_precision_score((rel > 0).astype(int), sc))
+    got = pkg.CustomRetrievalEvaluator(k_values=[1, 3, 5, 10, 50]).compute_mteb_metrics(qrels, results)
+    for k, vals in want_ndcg.items():
+        assert got["NDCG"][f"NDCG@{k}"] == pytest.approx(float(np.mean(vals)), abs=1.1e-5), k
+    assert got["mAP"]["MAP@50"] == pytest.approx(float(np.mean(want_map)), abs=1.1e-5)
