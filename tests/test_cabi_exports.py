@@ -65,3 +65,16 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_header_is_plain_c():
+    """include/evdr.h is the boundary a non-Python host binds: it must compile as C99 and as C++11 on its own."""
+    import shutil
+    import subprocess
+    header = os.path.join(ROOT, "include", "evdr.h")
+    for cc, std, lang in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "c++")):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not available")
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", lang, header],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

@@ -166,3 +166,36 @@ def test_corpus_from_npz_payload(dev, tmp_path):
     got16 = c16.score(Q.bfloat16().to(dev), qm.to(dev))
     want16 = O.maxsim_masked(Q.bfloat16().float(), Pn.bfloat16().float(), qm, pmask)
     assert (got16.cpu() - want16).abs().max().item() < 1e-4
+
+
+def test_config2_fp32_inputs_properties(dev):
+    """configs[2] at the reference's own dtype: 6847 pages x 1030 patches of genuinely fp32 (not bf16-representable)
+    embeddings through the drop-in scorer (fp16 hi/lo planes).  Sampled columns against an fp64 computation, the cached
+    prepared planes against a fresh preparation, row/column permutation equivariance, and bf16 rounding as a sanity
+    bound on how far a wrong plane product would be."""
+    from evdr_amd.evaluator import retrieval as ER
+    g = torch.Generator(device=dev).manual_seed(23)
+    n, nq = 6847, 48
+    P = torch.nn.functional.normalize(torch.randn((n, LP, D), generator=g, device=dev), dim=-1)
+    tgt = (torch.arange(nq, device=dev) * 7919) % n
+    eps = torch.nn.functional.normalize(torch.randn((nq, LQ, D), generator=g, device=dev), dim=-1)        # unit-norm noise
+    Q = torch.nn.functional.normalize(P[tgt, :LQ] + 0.3 * eps, dim=-1)
+    qm = torch.ones(nq, LQ, dtype=torch.bool, device=dev)
+    pm = torch.ones(n, LP, dtype=torch.bool, device=dev)
+    pm[::7, 900:] = False
+    ER.forget_prepared()
+    s = ER.score_multi_vector_masked(Q, P, qm, pm)
+    assert torch.equal(s.argmax(dim=1), tgt)                                   # planted page on top
+    cols = torch.randperm(n, generator=torch.Generator().manual_seed(3))[:24].to(dev)
+    sim = torch.einsum("qnd,pmd->qpnm", Q.double(), P[cols].double()).masked_fill(~pm[cols][None, :, None, :], -1e4)
+    want = sim.amax(-1).sum(-1)
+    assert (s[:, cols].double() - want).abs().max().item() < 5e-6              # fp32-level accuracy, 20x inside the 1e-4 gate
+    s2 = ER.score_multi_vector_masked(Q, P, qm, pm)                            # second call: cached planes
+    assert torch.equal(s, s2)
+    perm_q = torch.randperm(nq, device=dev)
+    perm_p = torch.randperm(n, device=dev)
+    s3 = ER.score_multi_vector_masked(Q[perm_q], P[perm_p], qm[perm_q], pm[perm_p])
+    assert torch.equal(s3, s[perm_q][:, perm_p])                               # same per-tensor scale, same arithmetic per pair
+    sb = ER.score_multi_vector_masked(Q.bfloat16(), P.bfloat16(), qm, pm)
+    assert 1e-4 < (sb - s).abs().max().item() < 0.1                            # bf16 rounding is visible, fp32 path is not that
+    ER.forget_prepared()
