@@ -24,3 +24,13 @@ import time
 torch.cuda.synchronize(); t0=time.perf_counter()
 for _ in range(50): ops.maxsim_backward(g, Q, qm, pm, arg, N, Ls)
 torch.cuda.synchronize(); print("wall per call us", (time.perf_counter()-t0)/50*1e6)
+# skewed argmax distributions: a few patches win most (query, token) pairs of a page
+import numpy as np
+def zipf():
+    return torch.from_numpy(np.random.default_rng(0).zipf(1.5, size=(B, N, Lq)).clip(max=Ls) - 1).long()
+def hot(frac):
+    return torch.where(torch.rand(B, N, Lq) < frac, torch.zeros(B, N, Lq, dtype=torch.long), torch.randint(0, Ls, (B, N, Lq)))
+for name, mk in (("zipf 1.5", zipf), ("30% on one row", lambda: hot(0.3)), ("10% on one row", lambda: hot(0.1))):
+    a = mk().to(dev)
+    a = ((a + torch.arange(N, device=dev)[None, :, None] * 7) % Ls).to(torch.int16).contiguous()      # the hot row differs per page
+    print(f"{name:16s} us", t(lambda: ops.maxsim_backward(g, Q, qm, pm, a, N, Ls)))
