@@ -12,12 +12,13 @@ namespace {
 constexpr int BW_THREADS = 512;
 constexpr int BW_ROWS_MAX = 256;      // patch rows of dP owned by one workgroup: 128 KiB of LDS (fp32 x 128)
 
-// One workgroup owns BW_ROWS consecutive patch rows of one page.  fp32 LDS atomics are NOT used: ds_add_f32 costs
-// ~175 cycles per wave-instruction on gfx950 (measured: 346 us with them, 28 us with plain read-modify-write on this
-// very kernel).  Instead the (query, token) pairs are bucketed by target row -- integer histogram, exclusive scan,
-// scatter: three small LDS passes per chunk of pairs -- and each 16-lane group then OWNS whole rows: it walks a row's
-// bucket with four 512-B query-row loads in flight, accumulates in registers and adds into the slab with plain LDS
-// accesses.  Every dP element is written to HBM exactly once; masked rows come out as exact zeros.
+// One workgroup owns BW_ROWS consecutive patch rows of one page.  fp32 LDS atomics are NOT the accumulation path:
+// ds_add_f32 costs ~175 cycles per wave-instruction on gfx950 (measured: 346 us with one atomic per pair, 28 us with plain
+// read-modify-write on this very kernel).  Instead the (query, token) pairs are bucketed by target row -- integer
+// histogram, exclusive scan, scatter: three small LDS passes per chunk of pairs -- and the sorted list is cut into equal
+// slices (snapped to bucket starts), one per 16-lane group: a group walks its slice with four 512-B query-row loads in
+// flight, accumulates a row in registers and adds it into the slab with plain LDS accesses; only a row heavier than a
+// whole slice is shared between groups, and only its partial sums go through LDS atomics.  Every dP element is written to HBM exactly once; masked rows come out as exact zeros.
 // The order of the additions inside one row follows the scatter order (not fixed run to run, like index_add_ on a GPU).
 // FUSED: instead of writing dP (the gradient w.r.t. the NORMALISED pages), the epilogue continues on the slab in LDS:
 // l2-normalise backward through y = m x / (||m x|| + eps_n)  ->  AdamW on the raw parameter x (torch semantics: decoupled
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
     int* hist = reinterpret_cast<int*>(wl + CHUNK);                      // [BW_ROWS] bucket sizes
     int* offs = hist + BW_ROWS;                                          // [BW_ROWS] bucket starts
     int* cur = offs + BW_ROWS;                                           // [BW_ROWS] scatter cursors
-    __shared__ int sh_has;
+    __shared__ int sh_has, sh_total;
     const int page = blockIdx.x;
     const int r0 = blockIdx.y * BW_ROWS;
     const int rows = min(BW_ROWS, lp - r0);
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
                 if (tid < BW_ROWS) offs[tid] += add;
                 __syncthreads();
             }
+            if (tid == BW_ROWS - 1) sh_total = offs[tid];  // all bucketed pairs of this chunk
             if (tid < BW_ROWS) offs[tid] -= v;            // inclusive -> exclusive
             __syncthreads();
             // (3) scatter the pairs into their buckets
@@ -117,36 +119,76 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
                 const int a = a_loc[k];
                 if (a >= 0) {
                     const int slot = offs[a] + atomicAdd(&cur[a], 1);
-                    list[slot] = k * BW_THREADS + tid;
+                    list[slot] = (k * BW_THREADS + tid) | (a << 16);       // pair inside the chunk | target row
                     wl[slot] = w_loc[k];
                 }
             }
             __syncthreads();
-            // (4) each 16-lane group owns rows gid, gid + NGROUPS, ...: registers accumulate, 4 row loads in flight
-            for (int r = gid; r < rows; r += NGROUPS) {
-                const int n = hist[r], o = offs[r];
-                if (n == 0) continue;
+            // (4) the bucketed list (pairs sorted by target row) is cut into NGROUPS equal slices, one per 16-lane group,
+            // whatever the distribution over rows: a patch that wins half of a page's (query, token) pairs -- salient
+            // patches do -- no longer serialises on one group (all pairs on one row: 220 us before, now the uniform-case
+            // time).  A group accumulates a row in registers with 4 query-row loads in flight and adds it into the slab when
+            // the row changes: plain read-modify-write if the whole bucket lies in its slice, LDS float atomics for a
+            // heavy row it shares with its neighbours.
+            {
+                const int total = sh_total;
+                const int per = ((total + NGROUPS - 1) / NGROUPS + 3) & ~3;
+                // slice boundary g: g * per, moved back to the start of the bucket it falls into unless that bucket is
+                // larger than a slice -- so only rows heavier than a slice are ever shared (and pay atomics)
+                auto boundary = [&](int gi) {
+                    const int x = gi * per;
+                    if (x <= 0) return 0;
+                    if (x >= total) return total;
+                    const int r = list[x] >> 16;
+                    return (hist[r] <= per) ? offs[r] : x;
+                };
+                const int lo = boundary(gid), hi = boundary(gid + 1);
+                int cur_row = -1;
                 f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-                for (int k = 0; k < n; k += 4) {
+                auto flush = [&]() {
+                    if (cur_row < 0) return;
+                    float* dst = acc + cur_row * EVDR_D + sub * 8;
+                    const int b0 = offs[cur_row];
+                    if (b0 >= lo && b0 + hist[cur_row] <= hi) {
+                        reinterpret_cast<f32x4*>(dst)[0] += s0;
+                        reinterpret_cast<f32x4*>(dst)[1] += s1;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            atomicAdd(dst + i, s0[i]);
+                            atomicAdd(dst + 4 + i, s1[i]);
+                        }
+                    }
+                };
+                for (int k = lo; k < hi; k += 4) {
                     f32x4 v0[4], v1[4];
                     float w4[4];
+                    int row4[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int kk = min(k + u, n - 1);
-                        const float* qrow = Q + (int64_t)(c0 + list[o + kk]) * EVDR_D + sub * 8;
-                        w4[u] = (k + u < n) ? wl[o + kk] : 0.f;
+                        const int kk = min(k + u, hi - 1);
+                        const int e = list[kk];
+                        const float* qrow = Q + (int64_t)(c0 + (e & 0xFFFF)) * EVDR_D + sub * 8;
+                        row4[u] = e >> 16;
+                        w4[u] = wl[kk];
                         v0[u] = *reinterpret_cast<const f32x4*>(qrow);
                         v1[u] = *reinterpret_cast<const f32x4*>(qrow + 4);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        s0 += v0[u] * w4[u];
-                        s1 += v1[u] * w4[u];
+                        if (k + u < hi) {
+                            if (row4[u] != cur_row) {
+                                flush();
+                                cur_row = row4[u];
+                                s0 = f32x4{0, 0, 0, 0};
+                                s1 = f32x4{0, 0, 0, 0};
+                            }
+                            s0 += v0[u] * w4[u];
+                            s1 += v1[u] * w4[u];
+                        }
                     }
                 }
-                f32x4* dst = reinterpret_cast<f32x4*>(acc + r * EVDR_D + sub * 8);
-                dst[0] += s0;
-                dst[1] += s1;
+                flush();
             }
             __syncthreads();
         }
