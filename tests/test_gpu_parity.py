@@ -204,6 +204,32 @@ def test_prepared_pages_cache(dev, ER):
     ER.forget_prepared()
 
 
+@pytest.mark.parametrize("frac", [1.0, 0.4])
+def test_a6_backward_hot_patch_row(dev, ER, frac):
+    """A salient patch that wins most (query, token) pairs of a page: the balanced backward splits that row's bucket over
+    several lane groups (partial sums through LDS atomics); dP and the fused AdamW update must not care."""
+    gen = torch.Generator().manual_seed(90)
+    B, Lq, N, Ls = 32, 32, 6, 100
+    u = torch.nn.functional.normalize(torch.randn(128, generator=gen), dim=0)
+    Q = torch.nn.functional.normalize(u + 0.15 * torch.randn(B, Lq, 128, generator=gen), dim=-1)
+    hot = torch.rand(B, Lq, generator=gen) < frac
+    Q = torch.where(hot[..., None], Q, torch.nn.functional.normalize(torch.randn(B, Lq, 128, generator=gen), dim=-1))
+    P = torch.nn.functional.normalize(torch.randn(N, Ls, 128, generator=gen), dim=-1)
+    P[:, 7] = u                                                           # every page: patch 7 is the salient one
+    qm = torch.rand(B, Lq, generator=gen) > 0.1
+    pm = torch.ones(N, Ls, dtype=torch.bool)
+    pm[2, 50:] = False
+    _, warg = O.maxsim_masked_argmax(Q, P, qm, pm)
+    assert (warg == 7).float().mean().item() > 0.8 * frac                 # the construction does concentrate the argmax
+    gsc = torch.randn(B, N, generator=gen)
+    Pd = P.to(dev).requires_grad_(True)
+    ER.score_multi_vector_masked(Q.to(dev), Pd, qm.to(dev), pm.to(dev)).backward(gsc.to(dev))
+    Pc = P.clone().requires_grad_(True)
+    O.maxsim_masked(Q, Pc, qm, pm).backward(gsc)
+    np.testing.assert_allclose(Pd.grad.cpu().numpy(), Pc.grad.numpy(), atol=5e-5, rtol=1e-5)
+    assert float(Pd.grad.cpu()[2, 50:].abs().max()) == 0.0                # masked rows: exact zeros
+
+
 def test_split_f32_planes(dev):
     """evdr_split_f32: hi + lo == x * 2^k to 2^-21 relative, k from the absmax word, which holds the bits of max|x|."""
     from evdr_amd import ops
