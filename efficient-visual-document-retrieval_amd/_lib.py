@@ -34,7 +34,8 @@ SIGNATURES = {
     "evdr_l2norm_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
     "evdr_l2norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
     "evdr_l2norm_fwd_split": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
-    "evdr_topk": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, C.c_int, _vp, _vp, _vp]),
+    "evdr_topk_workspace": (_sz, [_i64, _i64, C.c_int]),
+    "evdr_topk": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, C.c_int, _vp, _vp, _vp, _sz, _vp]),
     "evdr_maxsim_topk_workspace": (_sz, [_i64, _i64]),
     "evdr_maxsim_topk": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64, _vp, _vp, _i32, C.c_int,
                                    _vp, _vp, _vp, _sz, _vp]),

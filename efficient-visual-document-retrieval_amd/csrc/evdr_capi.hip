@@ -270,21 +270,29 @@ int evdr_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask_or_n
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "l2norm_bwd launch");
 }
 
+size_t evdr_topk_workspace(int64_t nq, int64_t n, int k) {
+    if (nq <= 0 || n <= 0 || k < 1) return 0;
+    const int nseg = evdr_topk_segments(nq, n);
+    return nseg == 1 ? 0 : align_up((size_t)nq * nseg * k * 8);
+}
+
 int evdr_topk(const float* scores, const int32_t* idx_map_or_null, int64_t nq, int64_t n, int64_t row_stride,
-              int32_t idx_base, int k, float* top_scores, int32_t* top_idx, void* hip_stream) {
+              int32_t idx_base, int k, float* top_scores, int32_t* top_idx, void* workspace_or_null, size_t workspace_bytes,
+              void* hip_stream) {
     if (nq < 0 || n < 0) return fail(EVDR_ERR_ARG, "negative size");
     if (k < 1 || k > EVDR_TOPK_MAX) return fail(EVDR_ERR_ARG, "k=%d outside 1..%d", k, EVDR_TOPK_MAX);
     if (nq == 0) return EVDR_OK;
     if (!top_scores || !top_idx || (n > 0 && !scores)) return fail(EVDR_ERR_ARG, "evdr_topk: null pointer");
     if (row_stride < n) return fail(EVDR_ERR_ARG, "row_stride < n");
+    if (workspace_or_null && workspace_bytes < evdr_topk_workspace(nq, n, k)) workspace_or_null = nullptr;   // too small: one level
     hipError_t e = evdr_launch_topk(scores, idx_map_or_null, nq, n, row_stride, idx_base, k, top_scores, top_idx,
-                                    (hipStream_t)hip_stream);
+                                    workspace_or_null, (hipStream_t)hip_stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "topk launch");
 }
 
 size_t evdr_maxsim_topk_workspace(int64_t nq, int64_t np) {
     if (nq < 0 || np < 0) return 0;
-    return align_up((size_t)nq * np * sizeof(float));
+    return align_up((size_t)nq * np * sizeof(float)) + evdr_topk_workspace(nq, np, EVDR_TOPK_MAX);
 }
 
 int evdr_maxsim_topk(const uint16_t* Qplanes, const uint16_t* Pplanes, const uint8_t* qmask, const uint32_t* tilemask,
@@ -299,7 +307,9 @@ int evdr_maxsim_topk(const uint16_t* Qplanes, const uint16_t* Pplanes, const uin
     int rc = evdr_maxsim_fwd_prepared(Qplanes, Pplanes, qmask, tilemask, pageflags, scores, np, nullptr, nq, lq, np, lp,
                                       nplanes, p_stride, p_plane_stride, q_amax_or_null, p_amax_or_null, hip_stream);
     if (rc != EVDR_OK) return rc;
-    return evdr_topk(scores, nullptr, nq, np, np, idx_base, k, top_scores, top_idx, hip_stream);
+    char* tkws = (char*)workspace + align_up((size_t)nq * np * sizeof(float));
+    return evdr_topk(scores, nullptr, nq, np, np, idx_base, k, top_scores, top_idx, tkws, evdr_topk_workspace(nq, np, EVDR_TOPK_MAX),
+                     hip_stream);
 }
 
 int evdr_infonce_distill_fwd_bwd(const float* score_s, const float* score_t, int64_t b, int64_t n, float temperature,

@@ -115,6 +115,7 @@ hipError_t evdr_launch_l2norm_bwd(const float* gy, const float* x, const uint8_t
                                   float eps, float* dx, hipStream_t stream);
 hipError_t evdr_launch_topk(const float* scores, const int32_t* idx_map, int64_t nq, int64_t n,
                             int64_t row_stride, int32_t idx_base, int k, float* top_scores, int32_t* top_idx,
-                            hipStream_t stream);
+                            void* workspace, hipStream_t stream);
+int evdr_topk_segments(int64_t nq, int64_t n);
 hipError_t evdr_launch_infonce(const float* ss, const float* st, int64_t b, int64_t n, float temperature,
                                float* loss, float* dscore, float* row_loss, hipStream_t stream);

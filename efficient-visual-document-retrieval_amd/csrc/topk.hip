@@ -27,9 +27,12 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
     return __builtin_bit_cast(float, u);
 }
 
+// nseg > 1: workgroup b ranks segment b % nseg (columns [seg * (b % nseg), +seg) of row b / nseg) and writes that segment's
+// k candidates; a second launch over the nseg * k candidates of each row (idx_map = their indices) finishes the job.  One
+// workgroup per row leaves 255 CUs idle when a handful of queries rank 100 k pages.
 __global__ void __launch_bounds__(TK_THREADS) topk_kernel(const float* __restrict__ scores,
-                                                         const int32_t* __restrict__ idx_map, int64_t n,
-                                                         int64_t row_stride, int32_t idx_base, int k,
+                                                         const int32_t* __restrict__ idx_map, int64_t n_total,
+                                                         int64_t row_stride, int32_t idx_base, int k, int nseg, int64_t seg,
                                                          float* __restrict__ top_scores,
                                                          int32_t* __restrict__ top_idx) {
     __shared__ uint32_t hist[TK_BINS];
@@ -39,9 +42,13 @@ __global__ void __launch_bounds__(TK_THREADS) topk_kernel(const float* __restric
     __shared__ uint32_t sh_eq_base;
 
     const int tid = threadIdx.x;
-    const int64_t rowi = blockIdx.x;
-    const float* row = scores + rowi * row_stride;
-    const int32_t* map = idx_map ? idx_map + rowi * n : nullptr;
+    const int64_t rowi = blockIdx.x / nseg;
+    const int64_t col0 = (int64_t)(blockIdx.x % nseg) * seg;
+    const int64_t n = max((int64_t)0, min(seg, n_total - col0));
+    const float* row = scores + rowi * row_stride + col0;
+    const int32_t* map = idx_map ? idx_map + rowi * n_total + col0 : nullptr;
+    idx_base += (int32_t)col0;
+    const int64_t orow = blockIdx.x;                 // output row: (row, segment)
     const int keff = (int)min((int64_t)k, n);
     // Row scan with 16-B loads, 16-32 elements in flight per thread (one workgroup has to keep enough bytes in flight to cover the
     // L2 latency: scalar loads left it at ~4 GB/s per row).  body(valid, key, index) is called the same number of times by
@@ -209,17 +216,39 @@ __global__ void __launch_bounds__(TK_THREADS) topk_kernel(const float* __restric
     if (tid < k) {
         const unsigned long long c = cand[tid];
         const bool real = tid < keff;
-        top_scores[rowi * k + tid] = real ? key_to_float((uint32_t)(c >> 32)) : -__builtin_inff();
-        top_idx[rowi * k + tid] = real ? (int32_t)(0xFFFFFFFFu - (uint32_t)c) : -1;
+        top_scores[orow * k + tid] = real ? key_to_float((uint32_t)(c >> 32)) : -__builtin_inff();
+        top_idx[orow * k + tid] = real ? (int32_t)(0xFFFFFFFFu - (uint32_t)c) : -1;
     }
 }
 
 }  // namespace
 
+// Segments per row for the two-level form (1 = one workgroup per row is enough): aim at ~512 workgroups of >= 4096 columns.
+int evdr_topk_segments(int64_t nq, int64_t n) {
+    if (nq >= 256 || n < 2 * 4096) return 1;
+    int64_t by_len = (n + 4095) / 4096, by_fill = 512 / (nq > 0 ? nq : 1);
+    int64_t s = by_len < by_fill ? by_len : by_fill;
+    return (int)(s < 1 ? 1 : s);
+}
+
 hipError_t evdr_launch_topk(const float* scores, const int32_t* idx_map, int64_t nq, int64_t n, int64_t row_stride,
-                            int32_t idx_base, int k, float* top_scores, int32_t* top_idx, hipStream_t stream) {
+                            int32_t idx_base, int k, float* top_scores, int32_t* top_idx, void* workspace,
+                            hipStream_t stream) {
     if (nq == 0) return hipSuccess;
-    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)nq), dim3(TK_THREADS), 0, stream, scores, idx_map, n, row_stride,
-                       idx_base, k, top_scores, top_idx);
+    const int nseg = workspace ? evdr_topk_segments(nq, n) : 1;
+    if (nseg == 1) {
+        hipLaunchKernelGGL(topk_kernel, dim3((unsigned)nq), dim3(TK_THREADS), 0, stream, scores, idx_map, n, row_stride,
+                           idx_base, k, 1, n, top_scores, top_idx);
+        return hipGetLastError();
+    }
+    const int64_t seg = ((n + nseg - 1) / nseg + 3) & ~(int64_t)3;            // keeps 16-B aligned rows aligned
+    float* cs = reinterpret_cast<float*>(workspace);                          // (nq, nseg * k) candidate scores
+    int32_t* ci = reinterpret_cast<int32_t*>(cs + nq * nseg * k);             // ... and their reported indices
+    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)(nq * nseg)), dim3(TK_THREADS), 0, stream, scores, idx_map, n, row_stride,
+                       idx_base, k, nseg, seg, cs, ci);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)nq), dim3(TK_THREADS), 0, stream, (const float*)cs, (const int32_t*)ci,
+                       (int64_t)nseg * k, (int64_t)nseg * k, 0, k, 1, (int64_t)nseg * k, top_scores, top_idx);
     return hipGetLastError();
 }

@@ -179,9 +179,11 @@ def topk(scores: torch.Tensor, k: int, idx_base: int = 0,
             raise RuntimeError("idx_map must have the shape of scores")
         im = idx_map.to(device=dev, dtype=torch.int32).contiguous()
     row_stride = scores.stride(0) if nq > 1 else max(n, 1)
+    wsb = lib.evdr_topk_workspace(nq, n, k)          # > 0: few long rows, ranked by many workgroups in two levels
+    ws = workspace(wsb, dev) if wsb else None
     with torch.cuda.device(dev):
         L.check(lib.evdr_topk(L.ptr(scores), L.ptr(im), nq, n, max(row_stride, n), idx_base, k, L.ptr(ts), L.ptr(ti),
-                              L.current_stream_handle(dev)))
+                              L.ptr(ws), wsb, L.current_stream_handle(dev)))
     return ts, ti
 
 

@@ -149,10 +149,14 @@ int evdr_l2norm_fwd_split(const float* x, const uint8_t* rowmask_or_null, int64_
  * scores (nq, n) fp32 with row stride `row_stride`; idx_map_or_null (nq, n) int32 maps a column to
  * the index to report (used when merging per-shard candidate lists), else column + idx_base.
  * Order: score descending, reported index ascending on ties.  k <= EVDR_TOPK_MAX.
- * top_scores/top_idx (nq, k); rows with n < k are padded with (-inf, -1). */
+ * top_scores/top_idx (nq, k); rows with n < k are padded with (-inf, -1).
+ * workspace_or_null (evdr_topk_workspace bytes; 0 = not needed): lets a few long rows be ranked by many workgroups
+ * (per-segment candidates, then a merge) instead of one workgroup per row; same result either way. */
+size_t evdr_topk_workspace(int64_t nq, int64_t n, int k);
 int evdr_topk(const float* scores, const int32_t* idx_map_or_null, int64_t nq, int64_t n,
               int64_t row_stride, int32_t idx_base, int k,
-              float* top_scores, int32_t* top_idx, void* hip_stream);
+              float* top_scores, int32_t* top_idx,
+              void* workspace_or_null, size_t workspace_bytes, void* hip_stream);
 
 /* A1 + A8 in one call on a prepared corpus: scores land in `workspace` (nq*np floats). */
 size_t evdr_maxsim_topk_workspace(int64_t nq, int64_t np);

@@ -88,7 +88,7 @@ int main() {
     }
     EV(evdr_maxsim_fwd(dQ, dP, (const uint8_t*)dqm, (const uint8_t*)dpm, (float*)dout, nullptr, nq, lq, np, lp, d, EVDR_BF16,
                        nullptr, dws, wsb, st));
-    EV(evdr_topk((const float*)dout, nullptr, nq, np, np, 100, k, (float*)dts, (int32_t*)dti, st));
+    EV(evdr_topk((const float*)dout, nullptr, nq, np, np, 100, k, (float*)dts, (int32_t*)dti, nullptr, 0, st));
     CK(hipStreamSynchronize(st));
     std::vector<float> got(nq * np), ts(nq * k);
     std::vector<int32_t> ti(nq * k);

@@ -50,7 +50,7 @@ def test_argument_errors_need_no_gpu(lib):
     assert rc == L.EVDR_ERR_ARG
     rc = lib.evdr_maxsim_fwd(None, None, None, None, None, None, 0, 8, 4, 8, 128, L.EVDR_BF16, None, None, 0, None)
     assert rc == L.EVDR_OK               # empty score matrix is fine
-    rc = lib.evdr_topk(None, None, 3, 10, 10, 0, 500, None, None, None)
+    rc = lib.evdr_topk(None, None, 3, 10, 10, 0, 500, None, None, None, 0, None)
     assert rc == L.EVDR_ERR_ARG and b"k=500" in lib.evdr_last_error()
     rc = lib.evdr_infonce_distill_fwd_bwd(None, None, 4, 4, ctypes.c_float(0.0), None, None, None, None)
     assert rc == L.EVDR_ERR_ARG

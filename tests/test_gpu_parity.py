@@ -450,7 +450,7 @@ def test_a6_query_gradient(dev, ER, case):
 
 
 # ---- top-k --------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,k", [(500, 100), (37, 100), (100, 100), (5000, 10), (100001, 100), (1, 1)])
+@pytest.mark.parametrize("n,k", [(500, 100), (37, 100), (100, 100), (5000, 10), (100001, 100), (1, 1), (20000, 128), (8193, 7)])
 def test_topk_vs_oracle(dev, n, k):
     import evdr_amd.ops as ops
     gen = torch.Generator().manual_seed(n + k)
@@ -469,6 +469,26 @@ def test_topk_vs_oracle(dev, n, k):
     assert torch.equal(gs.cpu()[:, :keff] + 0.0, ws + 0.0)
     if keff < k:
         assert torch.all(gi.cpu()[:, keff:] == -1) and torch.all(torch.isinf(gs.cpu()[:, keff:]))
+
+
+def test_topk_two_level_strided_and_mapped(dev):
+    """Few long rows take the two-level form (per-segment candidates, then a merge): row-strided input, idx_map and
+    idx_base must come out exactly as from one workgroup per row."""
+    import evdr_amd.ops as ops
+    gen = torch.Generator().manual_seed(12)
+    big = torch.randn(3, 40000, generator=gen).to(dev)
+    big[0, 100:30000:2] = 2.5                                            # ties that straddle segments
+    s = big[:, 5:30006]                                                  # row stride 40000, rows not 16-B aligned
+    ws, wi = O.topk_rows(s.cpu(), 100)
+    gs, gi = ops.topk(s, 100, idx_base=7)
+    assert torch.equal(gi.cpu(), wi + 7) and torch.equal(gs.cpu(), ws)
+    sc = s.contiguous()
+    idx_map = torch.randperm(sc.shape[1], generator=gen).to(torch.int32)[None, :].repeat(3, 1).to(dev)
+    ms, mi = ops.topk(sc, 50, idx_map=idx_map)
+    # reference: rank by (score desc, mapped index asc)
+    for r in range(3):
+        order = sorted(range(sc.shape[1]), key=lambda j: (-float(sc[r, j] + 0.0), int(idx_map[r, j])))[:50]
+        assert mi[r].tolist() == [int(idx_map[r, j]) for j in order]
 
 
 def test_topk_idx_map_and_base(dev):
