@@ -16,8 +16,9 @@
  *     be NULL for the default stream) and the call returns immediately (graph-capture safe);
  *   - D (embedding width) must be 128 (ColPali / ColQwen projection width);
  *   - masks are one byte per token, 0 = masked (torch.bool storage);
- *   - dtype: EVDR_F32 inputs are scored to fp32 accuracy (3-way bf16 split, 6 MFMA products,
- *     error ~1e-7 relative); EVDR_BF16 inputs are used as they are (products exact in fp32).
+ *   - dtype: EVDR_F32 inputs are scored to fp32 accuracy (fp16 hi/lo planes of the power-of-two-scaled
+ *     tensors, 3 MFMA products, error below the rounding noise of an fp32 accumulation); EVDR_BF16
+ *     inputs are used as they are (products exact in fp32).
  */
 #ifndef EVDR_H
 #define EVDR_H
