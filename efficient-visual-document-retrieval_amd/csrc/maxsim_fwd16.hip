@@ -744,12 +744,10 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
 hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes, bool want_argmax, int geom, hipStream_t stream) {
     const int ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     if (nplanes == 2) {                                  // 4-tile stages of 16-KiB tiles: 2 x 5 x 16 KiB = all 160 KiB of LDS
-        // QW = 2: in-block refill with the lane offsets rebuilt per piece (SPQ2): +12 % on the 32 x 500 teacher forward;
-        // geom 9 = A/B without it
-        if (want_argmax) {
-            if (qw == 2) return geom == 9 ? launch16s<2, 2, true, 4, 2, false, true>(p, stream) : launch16s<2, 2, true, 4, 2, false, true, 2, true>(p, stream);
-            return launch16s<1, 2, true, 4, 2, false, true>(p, stream);
-        }
+        // QW = 2 without argmax: in-block refill with the lane offsets rebuilt per piece (SPQ2): 283 -> 273 us on the 32 x 500
+        // teacher forward, +1..3 % on large problems; geom 9 = A/B without it.  The argmax instance is already 48 registers
+        // over budget and loses 7 us of 77 with it (rocprofv3 on the training step), so it refills at the top of the stage.
+        if (want_argmax) return qw == 2 ? launch16s<2, 2, true, 4, 2, false, true>(p, stream) : launch16s<1, 2, true, 4, 2, false, true>(p, stream);
         if (qw == 2) return geom == 9 ? launch16s<2, 2, false, 4, 2, false, true>(p, stream) : launch16s<2, 2, false, 4, 2, false, true, 2, true>(p, stream);
         return launch16s<1, 2, false, 4, 2, false, true>(p, stream);
     }
