@@ -743,10 +743,26 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
 // page length.
 hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes, bool want_argmax, int geom, hipStream_t stream) {
     const int ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
-    if (nplanes == 2) {                                  // 4-tile stages of 16-KiB tiles: 2 x 5 x 16 KiB = all 160 KiB of LDS
+    if (nplanes == 2) {
+        // 16-KiB tiles: 4-tile stages (2 x 5 x 16 KiB = all 160 KiB of LDS) or 3-tile stages, whichever sends fewer FULL tiles
+        // through the per-tile path: a stage runs as the straight-line block only if all its tiles are full, and a lone
+        // tail tile rides in the previous stage.  1030 patches = 33 tiles: 8 x 4 + tail; 206 patches = 7 tiles: 2 x 3 + tail
+        // (with 4-tile stages the second stage -- tiles 4, 5 and the 14-patch tail -- would be generic).
+        auto generic_full_tiles = [&](int st) {
+            const bool partial = (p.lp % EVDR_TILE_PATCHES) != 0;
+            const int r = ntiles % st;
+            if (r == 1 && ntiles > st) return partial ? 0 : 1;
+            if (r == 0) return partial ? st - 1 : 0;
+            return partial ? r - 1 : r;
+        };
+        const bool st3 = geom == 10 || (geom != 11 && generic_full_tiles(3) < generic_full_tiles(4));   // 10 / 11: A/B force
         // QW = 2 without argmax: in-block refill with the lane offsets rebuilt per piece (SPQ2): 283 -> 273 us on the 32 x 500
         // teacher forward, +1..3 % on large problems; geom 9 = A/B without it.  The argmax instance is already 48 registers
         // over budget and loses 7 us of 77 with it (rocprofv3 on the training step), so it refills at the top of the stage.
+        if (st3) {
+            if (want_argmax) return qw == 2 ? launch16s<2, 2, true, 3, 2, false, true>(p, stream) : launch16s<1, 2, true, 3, 2, false, true>(p, stream);
+            return qw == 2 ? launch16s<2, 2, false, 3, 2, false, true, 2, true>(p, stream) : launch16s<1, 2, false, 3, 2, false, true>(p, stream);
+        }
         if (want_argmax) return qw == 2 ? launch16s<2, 2, true, 4, 2, false, true>(p, stream) : launch16s<1, 2, true, 4, 2, false, true>(p, stream);
         if (qw == 2) return geom == 9 ? launch16s<2, 2, false, 4, 2, false, true>(p, stream) : launch16s<2, 2, false, 4, 2, false, true, 2, true>(p, stream);
         return launch16s<1, 2, false, 4, 2, false, true>(p, stream);
