@@ -509,7 +509,16 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
             const int nslot = slot == 0 ? NSTAGE - 1 : slot - 1;
             const bool refill = S + NSTAGE - 1 < nstages;
             const int t0 = k * ST;
-            const bool fast = active && (vlen - t0 * EVDR_TILE_PATCHES >= ST * EVDR_TILE_PATCHES);
+            // a stage runs as the straight-line block when all its ST tiles are fully valid: from the valid length for
+            // prefix-style pages, from the mask words (one scalar load each, before the block) for pages with holes -- e.g.
+            // a few masked text tokens in front of the image patches leave all but the first stage of a page fast
+            bool fast = active && (vlen - t0 * EVDR_TILE_PATCHES >= ST * EVDR_TILE_PATCHES);
+            if (vlen < 0 && active && t0 + ST <= p.ntiles) {
+                uint32_t all = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < ST; ++i) all &= tilemask_c[(int64_t)page * p.ntiles + t0 + i];
+                fast = (all == 0xFFFFFFFFu);
+            }
             // In-block refill: when this stage runs the straight-line block AND the next stage is a full one (all ST tiles
             // exist and lie inside the page rows), its LDS-DMA pieces are issued NPL per tile INSIDE the block, where their
             // scalar/address work hides under MFMAs; otherwise the refill is issued here, right after the barrier.
