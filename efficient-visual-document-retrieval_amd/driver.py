@@ -42,21 +42,25 @@ class TeacherScorer:
     def __init__(self, P_teacher_norm: torch.Tensor, pmask_teacher: torch.Tensor, cache_size: int = 0):
         self.corpus = PageCorpus.from_tensor(P_teacher_norm.detach().float(), pmask_teacher)
         self.cache: Optional[torch.Tensor] = None
-        self.have: Optional[torch.Tensor] = None
+        self.have: Optional[np.ndarray] = None          # host-side: which rows of the cache are filled (no device sync to ask)
         if cache_size > 0:
             dev = P_teacher_norm.device
             self.cache = torch.empty((cache_size, self.corpus.n_pages), dtype=torch.float32, device=dev)
-            self.have = torch.zeros(cache_size, dtype=torch.bool, device=dev)
+            self.have = np.zeros(cache_size, dtype=bool)
 
     @torch.no_grad()
     def scores(self, Qb: torch.Tensor, qmb: torch.Tensor, qidx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Teacher scores of the batch; with a cache and the batch's dataset indices `qidx` (a host tensor, as the
+        DataLoader hands them out) a pseudo-query is scored once per run -- the teacher is frozen, so the cached rows are
+        the same numbers (mainv2_iter_distill_infonce.py:282-283 recomputes them every epoch)."""
         if self.cache is None or qidx is None:
             return self.corpus.score(Qb.float(), qmb)
-        qidx = qidx.to(self.cache.device)
-        if not bool(self.have[qidx].all()):
-            self.cache[qidx] = self.corpus.score(Qb.float(), qmb)
-            self.have[qidx] = True
-        return self.cache[qidx]
+        idx_host = qidx.detach().cpu().numpy().astype(np.int64)
+        idx_dev = qidx.to(self.cache.device, non_blocking=True)
+        if not self.have[idx_host].all():
+            self.cache[idx_dev] = self.corpus.score(Qb.float(), qmb)
+            self.have[idx_host] = True
+        return self.cache[idx_dev]
 
 
 def train_one_step(Qb, qmb, teacher, pmask_teacher, Pbar_param, pmask_student, opt, temp: float, chunk_p: int = 64,
