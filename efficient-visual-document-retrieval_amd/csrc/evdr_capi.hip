@@ -27,7 +27,7 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int64_t ntiles_of(int64_t lp) { return (lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES; }
 
 struct FwdWorkspace {
-    size_t tilemask_off, pageflags_off, amax_off, qplanes_off, pplanes_off, total;
+    size_t tilemask_off, pageflags_off, qlist_off, amax_off, qplanes_off, pplanes_off, total;
 };
 
 FwdWorkspace carve_fwd(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype) {
@@ -37,6 +37,8 @@ FwdWorkspace carve_fwd(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype
     off = align_up(off + (size_t)np * ntiles_of(lp) * 4);
     w.pageflags_off = off;
     off = align_up(off + (size_t)np * 4);
+    w.qlist_off = off;                                  // later token slices: [0] = count, [1..nq] = compacted query indices
+    if (lq > 32) off = align_up(off + (size_t)(nq + 1) * 4);
     w.amax_off = off;                                   // [0] = Q's absmax bits, [1] = P's
     if (dtype == EVDR_F32) off = align_up(off + 2 * sizeof(uint32_t));
     w.qplanes_off = off;
@@ -62,7 +64,7 @@ int check_common(int64_t nq, int64_t lq, int64_t np, int64_t lp) {
 int run_fwd(const uint16_t* Qp, int64_t q_stride, int64_t q_plane_stride, const uint16_t* Pp, int64_t p_stride,
             int64_t p_plane_stride, const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
             float* out, int64_t out_stride, uint16_t* argmax, int64_t nq, int64_t lq, int64_t np, int64_t lp,
-            int nplanes, const uint32_t* q_amax, const uint32_t* p_amax, hipStream_t stream) {
+            int nplanes, const uint32_t* q_amax, const uint32_t* p_amax, int32_t* qlist_ws, hipStream_t stream) {
     const bool pack = (lq == 1 && nq > 1 && q_stride == EVDR_D);
     for (int64_t tok0 = 0; tok0 < lq; tok0 += 32) {
         EvdrFwdParams p{};
@@ -88,6 +90,13 @@ int run_fwd(const uint16_t* Qp, int64_t q_stride, int64_t q_plane_stride, const 
         p.lq_total = pack ? 32 : (int)lq;
         p.per_token = pack ? nq : 0;
         p.accumulate = tok0 > 0 ? 1 : 0;
+        if (tok0 > 0 && qlist_ws && qmask && !argmax) {
+            // queries padded to the longest of a set: only those with a valid token in this slice are scored again
+            hipError_t eq = evdr_launch_build_qlist(qmask, nq, lq, tok0, qlist_ws + 1, qlist_ws, stream);
+            if (eq != hipSuccess) return hip_fail(eq, "build_qlist launch");
+            p.qlist = qlist_ws + 1;
+            p.qcount = qlist_ws;
+        }
         hipError_t e = evdr_launch_maxsim_fwd(p, nplanes, argmax != nullptr, stream);
         if (e != hipSuccess) return hip_fail(e, "maxsim_fwd launch");
     }
@@ -148,7 +157,7 @@ int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const ui
     if (e != hipSuccess) return hip_fail(e, "pack_pmask launch");
     if (dtype == EVDR_BF16) {
         return run_fwd((const uint16_t*)Q, q_stride, 0, (const uint16_t*)P, p_stride, 0, qmask, tilemask, pageflags, out,
-                       np, argmax_or_null, nq, lq, np, lp, 1, nullptr, nullptr, stream);
+                       np, argmax_or_null, nq, lq, np, lp, 1, nullptr, nullptr, lq > 32 ? (int32_t*)(ws + w.qlist_off) : nullptr, stream);
     }
     if (q_stride != lq * EVDR_D || p_stride != lp * EVDR_D)
         return fail(EVDR_ERR_ARG, "fp32 inputs must be dense (make them contiguous before the call)");
@@ -158,7 +167,7 @@ int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const ui
     if ((e = evdr_launch_split_f32((const float*)Q, nq * lq, qpl, amax, stream)) != hipSuccess) return hip_fail(e, "split Q");
     if ((e = evdr_launch_split_f32((const float*)P, np * lp, ppl, amax + 1, stream)) != hipSuccess) return hip_fail(e, "split P");
     return run_fwd(qpl, lq * EVDR_D, nq * lq * EVDR_D, ppl, lp * EVDR_D, np * lp * EVDR_D, qmask, tilemask, pageflags, out,
-                   np, argmax_or_null, nq, lq, np, lp, 2, amax, amax + 1, stream);
+                   np, argmax_or_null, nq, lq, np, lp, 2, amax, amax + 1, lq > 32 ? (int32_t*)(ws + w.qlist_off) : nullptr, stream);
 }
 
 int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes, const uint8_t* qmask,
@@ -174,7 +183,7 @@ int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes, c
     if (out_stride < np || p_stride < lp * EVDR_D) return fail(EVDR_ERR_ARG, "stride smaller than the row it spans");
     return run_fwd(Qplanes, lq * EVDR_D, nq * lq * EVDR_D, Pplanes, p_stride, p_plane_stride, qmask, tilemask, pageflags, out,
                    out_stride, argmax_or_null, nq, lq, np, lp, nplanes, nplanes == 2 ? q_amax_or_null : nullptr,
-                   nplanes == 2 ? p_amax_or_null : nullptr, (hipStream_t)hip_stream);
+                   nplanes == 2 ? p_amax_or_null : nullptr, nullptr, (hipStream_t)hip_stream);
 }
 
 int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,

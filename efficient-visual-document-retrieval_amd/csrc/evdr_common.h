@@ -34,6 +34,8 @@ struct EvdrFwdParams {
     const uint32_t* q_amax;     // fp16 hi/lo planes (nplanes = 2): absmax bits of the fp32 tensor they were split from
     const uint32_t* p_amax;     //   (evdr_h2_shift gives the power-of-two the planes were scaled by); null = unscaled
     const uint8_t* qmask;       // (nq, lq) or null
+    const int32_t* qlist;       // later token slices: compacted indices of the queries with a valid token in the slice, or null
+    const int32_t* qcount;      //   ... and their number (device memory)
     const uint32_t* tilemask;   // (np, ntiles)
     const uint32_t* pageflags;  // (np)
     float* out;                 // (nq, out_stride)
@@ -96,6 +98,8 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes,
                                     hipStream_t stream);
 hipError_t evdr_launch_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, uint32_t* tilemask,
                                   uint32_t* pageflags, hipStream_t stream);
+hipError_t evdr_launch_build_qlist(const uint8_t* qmask, int64_t nq, int64_t lq, int64_t tok0, int32_t* qlist, int32_t* qcount,
+                                   hipStream_t stream);
 hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, hipStream_t stream);
 hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                   const uint16_t* argmax, float* dP, int64_t nq, int64_t lq, int64_t np,

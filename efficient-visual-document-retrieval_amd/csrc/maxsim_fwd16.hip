@@ -22,6 +22,21 @@ namespace {
 using namespace evdr;
 constexpr int TILE_BYTES = kTileBytes;
 
+// Queries q0 .. q0 + QW - 1 of a wave: themselves, or -- in a later 32-token slice of long queries -- entries of the
+// compacted list of queries that HAVE a valid token in the slice (p.qlist / p.qcount, built by build_qlist_kernel), so
+// that the slice costs in proportion to the long queries, not to all of them.
+template <int QW>
+__device__ __forceinline__ void resolve_queries(const EvdrFwdParams& p, int q0, int (&qreal)[QW]) {
+    const int n = p.qlist ? __builtin_amdgcn_readfirstlane(*p.qcount) : p.nq;
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+        const int qv = q0 + j;
+        int q = -1;
+        if (qv < n) q = p.qlist ? __builtin_amdgcn_readfirstlane(p.qlist[qv]) : qv;
+        qreal[j] = q;
+    }
+}
+
 // Flat per-tile schedule: WAVES waves per workgroup, ST 32-patch tiles per ring stage, NSTAGE ring slots over the
 // block's flat tile stream (stages ignore page boundaries).  Used for short pages (< 8 tiles, e.g. the compressed
 // student pages); long pages take maxsim_fwd16s_kernel below.
@@ -45,16 +60,18 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
 
     // ---- resident query fragments: bq[j][t][s]
     const int q0 = (qg * WAVES + wave) * QW;
-    const bool active = q0 < p.nq;
+    int qreal[QW];                                        // wave-uniform: the queries of this wave, -1 = none
+    resolve_queries<QW>(p, q0, qreal);
+    bool active = qreal[0] >= 0;
     bf16x8 bq[QW][2][4];
     float qwt[QW][2];
 #pragma unroll
     for (int j = 0; j < QW; ++j) {
-        const int q = q0 + j;
+        const int q = qreal[j];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int tok = 16 * t + c;
-            const bool ok = (q < p.nq) && (tok < p.lq);
+            const bool ok = (q >= 0) && (tok < p.lq);
             const int64_t row = (int64_t)q * p.q_stride + (int64_t)(p.tok0 + tok) * EVDR_D + g * 8;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -68,6 +85,25 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.accumulate && p.argmax == nullptr) {
+        // a later 32-token slice of long queries (queries padded to the longest of a set: most have no valid token here):
+        // a wave whose queries add nothing skips its MFMA work, a workgroup without any such query leaves at once
+        // (not when the argmax is wanted: that is defined for masked query tokens too)
+        float any = 0.f;
+#pragma unroll
+        for (int j = 0; j < QW; ++j) any += qwt[j][0] + qwt[j][1];
+        active = active && (__ballot(any != 0.f) != 0ull);
+        // workgroup-wide OR through the first word of the (not yet used) ring: the fp16 instances own all 160 KiB of LDS as
+        // dynamic memory, a static flag (__syncthreads_or) would push them over the limit
+        volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(smem);
+        if (threadIdx.x == 0) *flag = 0u;
+        __syncthreads();
+        if (active && lane == 0) *flag = 1u;
+        __syncthreads();
+        const bool wg_active = *flag != 0u;
+        __syncthreads();
+        if (!wg_active) return;
+    }
 
     const uint32_t smem_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     auto issue_stage = [&](int s, int slot) {
@@ -193,8 +229,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
                                 cs += xgroup_max(run[j][t]) * has * qwt[j][t];
                             }
                             cs = row16_sum(cs);
-                            if (lane == 0 && q0 + j < p.nq) {
-                                float* o = p.out + (int64_t)(q0 + j) * p.out_stride + page;
+                            if (lane == 0 && qreal[j] >= 0) {
+                                float* o = p.out + (int64_t)qreal[j] * p.out_stride + page;
                                 if (p.accumulate) atomicAdd(o, cs);
                                 else *o = cs;
                             }
@@ -306,17 +342,19 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
     if constexpr (DIAG) d_t0 = stamp();
 
     const int q0 = (qg * WAVES + wave) * QW;
-    const bool active = q0 < p.nq;
+    int qreal[QW];                                        // wave-uniform: the queries of this wave, -1 = none
+    resolve_queries<QW>(p, q0, qreal);
+    bool active = qreal[0] >= 0;
     frag bq[QW][NPL][2][4];
     float qwt[QW][2];
 #pragma unroll
     for (int j = 0; j < QW; ++j) {
-        const int q = q0 + j;
+        const int q = qreal[j];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int tok = 16 * t + c;
             // per_token: "query" q is the pack of single-token queries 32 q .. 32 q + 31, the last pack may be short
-            const bool ok = (q < p.nq) && (tok < p.lq) && (!p.per_token || (int64_t)q * 32 + tok < p.per_token);
+            const bool ok = (q >= 0) && (tok < p.lq) && (!p.per_token || (int64_t)q * 32 + tok < p.per_token);
             const int64_t row = (int64_t)q * p.q_stride + (int64_t)(p.tok0 + tok) * EVDR_D + g * 8;
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl)
@@ -339,6 +377,22 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
         inv = __builtin_ldexpf(1.f, -(kq + kp));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.accumulate && p.argmax == nullptr) {          // later 32-token slice: see maxsim_fwd16_kernel
+        float any = 0.f;
+#pragma unroll
+        for (int j = 0; j < QW; ++j) any += qwt[j][0] + qwt[j][1];
+        active = active && (__ballot(any != 0.f) != 0ull);
+        // workgroup-wide OR through the first word of the (not yet used) ring: the fp16 instances own all 160 KiB of LDS as
+        // dynamic memory, a static flag (__syncthreads_or) would push them over the limit
+        volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(smem);
+        if (threadIdx.x == 0) *flag = 0u;
+        __syncthreads();
+        if (active && lane == 0) *flag = 1u;
+        __syncthreads();
+        const bool wg_active = *flag != 0u;
+        __syncthreads();
+        if (!wg_active) return;
+    }
 
     const uint32_t smem_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     // stage S = page (S / spp), tiles ST (S % spp) .. of that page (rows beyond the page are clamped: masked anyway)
@@ -686,23 +740,23 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                     const int tok = 16 * t + c;
                     if (p.per_token) {
                         // packed single-token queries: one score (and argmax) per token, no sum over the pack
-                        const int64_t qrow = (int64_t)(q0 + j) * 32 + tok;
-                        if (g == 0 && q0 + j < p.nq && qrow < p.per_token) {
+                        const int64_t qrow = (int64_t)qreal[j] * 32 + tok;
+                        if (g == 0 && qreal[j] >= 0 && qrow < p.per_token) {
                             p.out[qrow * p.out_stride + page] = v * has * qwt[j][t];
                             if constexpr (ARGMAX) p.argmax[qrow * p.np + page] = (uint16_t)bi;
                         }
                         continue;
                     }
                     if constexpr (ARGMAX) {
-                        if (g == 0 && tok < p.lq && q0 + j < p.nq)
-                            p.argmax[((int64_t)(q0 + j) * p.np + page) * p.lq_total + p.tok0 + tok] = (uint16_t)bi;
+                        if (g == 0 && tok < p.lq && qreal[j] >= 0)
+                            p.argmax[((int64_t)qreal[j] * p.np + page) * p.lq_total + p.tok0 + tok] = (uint16_t)bi;
                     }
                     cs += v * has * qwt[j][t];
                 }
                 if (p.per_token) continue;
                 cs = row16_sum(cs);
-                if (lane == 0 && q0 + j < p.nq) {
-                    float* o = p.out + (int64_t)(q0 + j) * p.out_stride + page;
+                if (lane == 0 && qreal[j] >= 0) {
+                    float* o = p.out + (int64_t)qreal[j] * p.out_stride + page;
                     if (p.accumulate) atomicAdd(o, cs);
                     else *o = cs;
                 }

@@ -90,6 +90,33 @@ __global__ void __launch_bounds__(256) split_h2_kernel(const float* __restrict__
     }
 }
 
+// Stable compaction of the queries that have a valid token in [tok0, tok0 + 32): one workgroup, 256 queries per round.
+__global__ void __launch_bounds__(256) build_qlist_kernel(const uint8_t* __restrict__ qmask, int nq, int lq, int tok0,
+                                                         int32_t* __restrict__ qlist, int32_t* __restrict__ qcount) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    const int hi = min(lq, tok0 + 32);
+    for (int q0 = 0; q0 < nq; q0 += 256) {
+        const int q = q0 + tid;
+        bool live = false;
+        if (q < nq)
+            for (int t = tok0; t < hi; ++t) live |= qmask[(int64_t)q * lq + t] != 0;
+        const unsigned long long bal = __ballot(live);
+        if (lane == 0) wave_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = base;
+        for (int w = 0; w < wv; ++w) before += wave_cnt[w];
+        if (live) qlist[before + __popcll(bal & ((1ull << lane) - 1ull))] = q;
+        __syncthreads();
+        if (tid == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) *qcount = base;
+}
+
 }  // namespace
 
 hipError_t evdr_launch_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, uint32_t* tilemask,
@@ -97,6 +124,12 @@ hipError_t evdr_launch_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, 
     const int ntiles = (int)((lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES);
     hipLaunchKernelGGL(pack_pmask_kernel, dim3((unsigned)np), dim3(64), 0, stream, pmask, (int)np, (int)lp, ntiles,
                        tilemask, pageflags);
+    return hipGetLastError();
+}
+
+hipError_t evdr_launch_build_qlist(const uint8_t* qmask, int64_t nq, int64_t lq, int64_t tok0, int32_t* qlist, int32_t* qcount,
+                                   hipStream_t stream) {
+    hipLaunchKernelGGL(build_qlist_kernel, dim3(1), dim3(256), 0, stream, qmask, (int)nq, (int)lq, (int)tok0, qlist, qcount);
     return hipGetLastError();
 }
 

@@ -230,6 +230,31 @@ def test_a6_backward_hot_patch_row(dev, ER, frac):
     assert float(Pd.grad.cpu()[2, 50:].abs().max()) == 0.0                # masked rows: exact zeros
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("lp", [40, 300])
+def test_a1_queries_padded_beyond_32_tokens(dev, ER, dt, lp):
+    """Queries padded to the longest of a set (50 tokens), most of them shorter than 32: the second 32-token slice runs on
+    the compacted list of long queries only (and not at all for workgroups without one); scores of every query, long or
+    short, empty or full, against the oracle."""
+    gen = torch.Generator().manual_seed(300 + lp)
+    nq, npg, lq = 77, 21, 50
+    lens = torch.randint(1, 33, (nq,), generator=gen)
+    lens[[3, 40, 41, 76]] = torch.tensor([50, 33, 47, 34])          # a few long ones, scattered over the wave slots
+    lens[5] = 0                                                     # a query with no valid token at all
+    qm = torch.arange(lq)[None, :] < lens[:, None]
+    Q = torch.nn.functional.normalize(torch.randn(nq, lq, 128, generator=gen), dim=-1)
+    P = torch.nn.functional.normalize(torch.randn(npg, lp, 128, generator=gen), dim=-1)
+    pm = torch.rand(npg, lp, generator=gen) > 0.2
+    if dt == torch.bfloat16:
+        Q, P = Q.bfloat16().float(), P.bfloat16().float()
+    want = O.maxsim_masked(Q, P, qm, pm)
+    got = ER.score_multi_vector_masked(Q.to(dev, dt), P.to(dev, dt), qm.to(dev), pm.to(dev))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=SCORE_ATOL)
+    assert got[5].abs().max().item() == 0.0
+    got_all = ER.score_multi_vector_masked(Q.to(dev, dt), P.to(dev, dt), torch.ones(nq, lq, dtype=torch.bool, device=dev), pm.to(dev))
+    np.testing.assert_allclose(got_all.cpu().numpy(), O.maxsim_masked(Q, P, torch.ones(nq, lq, dtype=torch.bool), pm).numpy(), atol=SCORE_ATOL)
+
+
 def test_split_f32_planes(dev):
     """evdr_split_f32: hi + lo == x * 2^k to 2^-21 relative, k from the absmax word, which holds the bits of max|x|."""
     from evdr_amd import ops
