@@ -24,7 +24,7 @@ SIGNATURES = {
     "evdr_maxsim_fwd_workspace": (_sz, [_i64, _i64, _i64, _i64, C.c_int]),
     "evdr_maxsim_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
     "evdr_maxsim_fwd_prepared": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64,
-                                           _vp, _vp, _vp]),
+                                           _vp, _vp, _vp, _vp]),
     "evdr_maxsim_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     "evdr_maxsim_bwd_q_workspace": (_sz, [_i64, _i64]),
     "evdr_maxsim_bwd_q": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
@@ -49,7 +49,7 @@ class EvdrError(RuntimeError):
         self.code = code
 
 
-ABI_VERSION = 200                  # EVDR_VERSION_NUM of csrc/evdr_common.h these signatures belong to
+ABI_VERSION = 201                  # EVDR_VERSION_NUM of csrc/evdr_common.h these signatures belong to
 
 _lib: Optional[C.CDLL] = None
 

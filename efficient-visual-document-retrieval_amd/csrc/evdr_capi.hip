@@ -174,7 +174,7 @@ int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes, c
                              const uint32_t* tilemask, const uint32_t* pageflags, float* out, int64_t out_stride,
                              uint16_t* argmax_or_null, int64_t nq, int64_t lq, int64_t np, int64_t lp, int nplanes,
                              int64_t p_stride, int64_t p_plane_stride, const uint32_t* q_amax_or_null,
-                             const uint32_t* p_amax_or_null, void* hip_stream) {
+                             const uint32_t* p_amax_or_null, int32_t* qlist_ws_or_null, void* hip_stream) {
     if (int rc = check_common(nq, lq, np, lp)) return rc;
     if (nplanes != 1 && nplanes != 2) return fail(EVDR_ERR_ARG, "nplanes must be 1 (bf16) or 2 (fp16 hi/lo)");
     if (nq == 0 || np == 0) return EVDR_OK;
@@ -183,7 +183,7 @@ int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes, c
     if (out_stride < np || p_stride < lp * EVDR_D) return fail(EVDR_ERR_ARG, "stride smaller than the row it spans");
     return run_fwd(Qplanes, lq * EVDR_D, nq * lq * EVDR_D, Pplanes, p_stride, p_plane_stride, qmask, tilemask, pageflags, out,
                    out_stride, argmax_or_null, nq, lq, np, lp, nplanes, nplanes == 2 ? q_amax_or_null : nullptr,
-                   nplanes == 2 ? p_amax_or_null : nullptr, nullptr, (hipStream_t)hip_stream);
+                   nplanes == 2 ? p_amax_or_null : nullptr, lq > 32 ? qlist_ws_or_null : nullptr, (hipStream_t)hip_stream);
 }
 
 int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
@@ -314,7 +314,7 @@ int evdr_maxsim_topk(const uint16_t* Qplanes, const uint16_t* Pplanes, const uin
                     evdr_maxsim_topk_workspace(nq, np), workspace_bytes);
     float* scores = (float*)workspace;
     int rc = evdr_maxsim_fwd_prepared(Qplanes, Pplanes, qmask, tilemask, pageflags, scores, np, nullptr, nq, lq, np, lp,
-                                      nplanes, p_stride, p_plane_stride, q_amax_or_null, p_amax_or_null, hip_stream);
+                                      nplanes, p_stride, p_plane_stride, q_amax_or_null, p_amax_or_null, nullptr, hip_stream);
     if (rc != EVDR_OK) return rc;
     char* tkws = (char*)workspace + align_up((size_t)nq * np * sizeof(float));
     return evdr_topk(scores, nullptr, nq, np, np, idx_base, k, top_scores, top_idx, tkws, evdr_topk_workspace(nq, np, EVDR_TOPK_MAX),

@@ -6,7 +6,7 @@
 
 #include "../../include/evdr.h"
 
-#define EVDR_VERSION_NUM 200   /* 0.2.0: fp16 hi/lo planes + absmax words in the prepared API, l2norm_fwd_split, adamw_advance */
+#define EVDR_VERSION_NUM 201   /* 0.2.1: fp16 hi/lo planes + absmax words, l2norm_fwd_split, adamw_advance, top-k workspace, qlist scratch */
 
 #define EVDR_D 128              /* embedding width the kernels are specialised for */
 #define EVDR_TILE_PATCHES 32    /* patches per LDS tile (two 16-row MFMA halves) */

@@ -135,12 +135,13 @@ def maxsim_forward_prepared(qplanes: torch.Tensor, qamax: Optional[torch.Tensor]
     if nq == 0 or npg == 0:
         return view, arg
     qm = _mask_u8(qmask, (nq, lq), dev)
+    qlist = torch.empty((nq + 1,), dtype=torch.int32, device=dev) if (lq > 32 and qm is not None and not want_argmax) else None
     lib = L.load()
     with torch.cuda.device(dev):
         L.check(lib.evdr_maxsim_fwd_prepared(
             L.ptr(qplanes), L.ptr(pplanes), L.ptr(qm), L.ptr(tilemask), L.ptr(pageflags), view.data_ptr(), out.stride(0),
             L.ptr(arg), nq, lq, npg, lp, nplanes, int(pplanes.stride(1)), int(pplanes.stride(0)), L.ptr(qamax), L.ptr(pamax),
-            L.current_stream_handle(dev)))
+            L.ptr(qlist), L.current_stream_handle(dev)))
     return view, arg
 
 

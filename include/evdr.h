@@ -85,14 +85,15 @@ int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const ui
  * (nplanes, nq, lq, 128); P planes are nplanes slabs `p_plane_stride` elements apart, each
  * (np, lp, 128) with `p_stride` elements between pages.  out row stride = out_stride floats, so a
  * shard can write its column block of a wider (nq, N) matrix.  This is the bench / retrieval
- * hot path (SURVEY §8(d),(e)). */
+ * hot path (SURVEY §8(d),(e)).  qlist_ws_or_null: (nq + 1) int32 of scratch, used when lq > 32 to score the later
+ * 32-token slices only for the queries that have valid tokens there (query sets are padded to their longest member). */
 int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes,
                              const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
                              float* out, int64_t out_stride, uint16_t* argmax_or_null,
                              int64_t nq, int64_t lq, int64_t np, int64_t lp,
                              int nplanes, int64_t p_stride, int64_t p_plane_stride,
                              const uint32_t* q_amax_or_null, const uint32_t* p_amax_or_null,
-                             void* hip_stream);
+                             int32_t* qlist_ws_or_null, void* hip_stream);
 
 /* ---- A6: autograd of A1 w.r.t. P (loss.backward(), mainv2_iter_distill_infonce.py:290) ---------------
  * dP[p,m,:] = sum_{q,n} g[q,p] * qmask[q,n] * has(p) * [m == argmax[q,p,n]] * Q[q,n,:]

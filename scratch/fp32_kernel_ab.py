@@ -15,7 +15,7 @@ for nq, np_, lp, am in [(32, 500, 1030, False), (32, 500, 206, True), (32, 500, 
     st = L.current_stream_handle(dev)
     def call():
         L.check(lib.evdr_maxsim_fwd_prepared(L.ptr(qp), L.ptr(pp), None, L.ptr(tm), L.ptr(pf), L.ptr(out), np_, L.ptr(arg), nq, 32, np_, lp, 2,
-                                             lp * 128, np_ * lp * 128, L.ptr(qa), L.ptr(pa), st))
+                                             lp * 128, np_ * lp * 128, L.ptr(qa), L.ptr(pa), None, st))
     line = f"nq={nq:4d} np={np_:5d} lp={lp:5d} argmax={int(am)}"
     for v in variants:
         os.environ["EVDR_FWD_VARIANT"] = str(v)

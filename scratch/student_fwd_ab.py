@@ -12,7 +12,7 @@ for nq, np_, lp, am in [(32, 500, 206, True), (32, 500, 206, False), (500, 6847,
     st = L.current_stream_handle(dev)
     def call():
         L.check(lib.evdr_maxsim_fwd_prepared(L.ptr(qp), L.ptr(pp), None, L.ptr(tm), L.ptr(pf), L.ptr(out), np_, L.ptr(arg), nq, 32, np_, lp, 2,
-                                             lp * 128, np_ * lp * 128, L.ptr(qa), L.ptr(pa), st))
+                                             lp * 128, np_ * lp * 128, L.ptr(qa), L.ptr(pa), None, st))
     tot = {"10": 0.0, "11": 0.0}; ref = None
     for rep in range(6):
         for v in ("10", "11"):

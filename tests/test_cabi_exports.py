@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.evdr_version() == 200
+    assert lib.evdr_version() == 201
     assert isinstance(lib.evdr_last_error(), bytes)
 
 
