@@ -231,15 +231,15 @@ def test_a6_backward_hot_patch_row(dev, ER, frac):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("lp", [40, 300])
-def test_a1_queries_padded_beyond_32_tokens(dev, ER, dt, lp):
+@pytest.mark.parametrize("lp,lq", [(40, 50), (300, 50), (300, 70)])
+def test_a1_queries_padded_beyond_32_tokens(dev, ER, dt, lp, lq):
     """Queries padded to the longest of a set (50 tokens), most of them shorter than 32: the second 32-token slice runs on
     the compacted list of long queries only (and not at all for workgroups without one); scores of every query, long or
     short, empty or full, against the oracle."""
-    gen = torch.Generator().manual_seed(300 + lp)
-    nq, npg, lq = 77, 21, 50
+    gen = torch.Generator().manual_seed(300 + lp + lq)
+    nq, npg = 77, 21
     lens = torch.randint(1, 33, (nq,), generator=gen)
-    lens[[3, 40, 41, 76]] = torch.tensor([50, 33, 47, 34])          # a few long ones, scattered over the wave slots
+    lens[[3, 40, 41, 76]] = torch.tensor([lq, 33, lq - 3, 34])      # a few long ones, scattered over the wave slots
     lens[5] = 0                                                     # a query with no valid token at all
     qm = torch.arange(lq)[None, :] < lens[:, None]
     Q = torch.nn.functional.normalize(torch.randn(nq, lq, 128, generator=gen), dim=-1)
