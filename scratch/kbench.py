@@ -5,7 +5,7 @@ sys.path.insert(0, "."); import evdr_amd
 from evdr_amd.corpus import PageCorpus
 sys.path.insert(0, "."); import bench as B
 pages = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-variants = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0,100").split(",")]
+variants = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "0,1,2").split(",")]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 zero = len(sys.argv) > 4 and sys.argv[4] == 'zero'
 dev = torch.device("cuda:0")

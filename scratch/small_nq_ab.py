@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, "."); import evdr_amd, bench as B
 from evdr_amd.corpus import PageCorpus
 dev = torch.device("cuda:0"); pages = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
-variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,3".split(","))]
+variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1".split(","))]
 P = B.gen_pages(0, pages, dev); corpus = PageCorpus.from_tensor(P, None)
 Qall, _ = B.make_queries(64, pages, P, 0, pages, dev, 1)
 ref = {}
