@@ -255,6 +255,24 @@ def test_a1_queries_padded_beyond_32_tokens(dev, ER, dt, lp, lq):
     np.testing.assert_allclose(got_all.cpu().numpy(), O.maxsim_masked(Q, P, torch.ones(nq, lq, dtype=torch.bool), pm).numpy(), atol=SCORE_ATOL)
 
 
+def test_a1_many_queries_few_pages(dev, ER):
+    """The teacher-score precompute shape of the training scripts (tens of thousands of pseudo-queries against a small
+    page set): thousands of query groups per page chunk, a single page, and the padded-slice path at that scale."""
+    gen = torch.Generator().manual_seed(31)
+    nq, npg, lq, lp = 20011, 3, 40, 45
+    Q = torch.nn.functional.normalize(torch.randn(nq, lq, 128, generator=gen), dim=-1).bfloat16()
+    P = torch.nn.functional.normalize(torch.randn(npg, lp, 128, generator=gen), dim=-1).bfloat16()
+    lens = torch.randint(1, 41, (nq,), generator=gen)
+    qm = torch.arange(lq)[None, :] < lens[:, None]
+    pm = torch.rand(npg, lp, generator=gen) > 0.3
+    got = ER.score_multi_vector_masked(Q.to(dev), P.to(dev), qm.to(dev), pm.to(dev)).cpu()
+    sel = torch.randperm(nq, generator=gen)[:400]
+    want = O.maxsim_masked(Q[sel].float(), P.float(), qm[sel], pm)
+    np.testing.assert_allclose(got[sel].numpy(), want.numpy(), atol=SCORE_ATOL)
+    one = ER.score_multi_vector_masked(Q[:700].to(dev), P[:1].to(dev), qm[:700].to(dev), pm[:1].to(dev)).cpu()
+    assert torch.equal(one[:, 0], got[:700, 0])                    # a single page: the same numbers as inside the larger call
+
+
 def test_split_f32_planes(dev):
     """evdr_split_f32: hi + lo == x * 2^k to 2^-21 relative, k from the absmax word, which holds the bits of max|x|."""
     from evdr_amd import ops
