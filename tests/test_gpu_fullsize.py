@@ -199,3 +199,43 @@ def test_config2_fp32_inputs_properties(dev):
     sb = ER.score_multi_vector_masked(Q.bfloat16(), P.bfloat16(), qm, pm)
     assert 1e-4 < (sb - s).abs().max().item() < 0.1                            # bf16 rounding is visible, fp32 path is not that
     ER.forget_prepared()
+
+
+def test_kernel_rate_floors(dev):
+    """Guard rails, not measurements: floors far below what every box of the pool delivered in round 1 (bf16 1735-1850
+    TFLOP/s, fp32 1570-1620, single-query streaming 5.6-6.3 TB/s), so that a change which throws a hot kernel off its
+    schedule (register spills in the straight-line block, a drained ring) fails loudly instead of costing 30 % silently."""
+    import evdr_amd.ops as ops
+    from evdr_amd.corpus import PageCorpus
+
+    def best_ms(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        out = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            out.append(a.elapsed_time(b))
+        return min(out)
+
+    P, Q, _ = synth(12000, 1024, dev, seed=21)
+    corpus = PageCorpus.from_tensor(P)
+    out = torch.empty((1024, 12000), dtype=torch.float32, device=dev)
+    ms = best_ms(lambda: corpus.score(Q, None, out=out))
+    tf = 1024 * 12000 * 2 * LQ * LP * D / ms / 1e9
+    assert tf > 1300, f"bf16 MaxSim kernel at {tf:.0f} TFLOP/s"
+    ms1 = best_ms(lambda: corpus.score(Q[:1], None, out=out[:1]))
+    tbs = 12000 * LP * D * 2 / ms1 / 1e9
+    assert tbs > 3.5, f"single-query corpus streaming at {tbs:.2f} TB/s"
+    g = torch.Generator(device=dev).manual_seed(22)
+    P32 = torch.nn.functional.normalize(torch.randn((2000, LP, D), generator=g, device=dev), dim=-1)
+    Q32 = torch.nn.functional.normalize(torch.randn((512, LQ, D), generator=g, device=dev), dim=-1)
+    c32 = PageCorpus.from_tensor(P32)
+    o32 = torch.empty((512, 2000), dtype=torch.float32, device=dev)
+    qp, qa = ops.split_f32(Q32)
+    ms32 = best_ms(lambda: ops.maxsim_forward_prepared(qp, qa, c32.planes, c32.amax, None, c32.tilemask, c32.pageflags, out=o32))
+    tf32 = 512 * 2000 * 2 * LQ * LP * D * 3 / ms32 / 1e9
+    assert tf32 > 1000, f"fp32 (fp16 hi/lo) MaxSim kernel at {tf32:.0f} TFLOP/s of plane products"
