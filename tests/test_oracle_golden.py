@@ -117,3 +117,53 @@ def test_metrics_closed_form():
     assert m["mRR"]["MRR@10"] == round((1 / 4 + 1 + 1 / 10) / 3, 5)
     assert m["Precision"]["P@5"] == round((1 / 5 + 1 / 5 + 0) / 3, 5)
     assert m["mAP"]["MAP@5"] == round((1 / 4 + 1 + 0) / 3, 5)
+
+
+def test_c_oracle_matches_reference_fixtures_and_torch_oracle(golden):
+    """oracle/maxsim_oracle.c (plain C, double accumulation) against the fixtures the reference's own function produced,
+    and against the torch restatement on a masked random case incl. an all-masked page and the argmax tie rule."""
+    import ctypes
+    import os
+    import shutil
+    import sys
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    lib = ctypes.CDLL(ge.build_oracle_c())
+    fn = lib.evdr_oracle_maxsim
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
+
+    def run(Q, P, qm, pm, want_arg=False):
+        Qc = np.ascontiguousarray(Q, dtype=np.float32)
+        Pc = np.ascontiguousarray(P, dtype=np.float32)
+        qmc = np.ascontiguousarray(qm, dtype=np.uint8)
+        pmc = np.ascontiguousarray(pm, dtype=np.uint8)
+        nq, lq, d = Qc.shape
+        npg, lp, _ = Pc.shape
+        out = np.empty((nq, npg), dtype=np.float64)
+        arg = np.empty((nq, npg, lq), dtype=np.int32) if want_arg else None
+        fn(Qc.ctypes.data, Pc.ctypes.data, qmc.ctypes.data, pmc.ctypes.data, nq, lq, npg, lp, d, out.ctypes.data,
+           arg.ctypes.data if want_arg else None)
+        return out, arg
+
+    for case in ("small_ragged", "lq1", "chunk_tail"):
+        z = golden(f"a1_{case}")
+        out, arg = run(z["Q"], z["P"], z["qmask"], z["pmask"], want_arg=True)
+        np.testing.assert_allclose(out, z["scores"], atol=2e-5)
+        live = z["qmask"].astype(bool)[:, None, :] & z["pmask"].astype(bool).any(-1)[None, :, None]
+        assert np.array_equal(arg[live], z["argmax"][live])
+    gen = torch.Generator().manual_seed(4)
+    Q = torch.nn.functional.normalize(torch.randn(5, 9, 128, generator=gen), dim=-1)
+    P = torch.nn.functional.normalize(torch.randn(7, 33, 128, generator=gen), dim=-1)
+    P[2, 5] = P[2, 1]                                              # exact tie: the first index wins
+    qm = torch.rand(5, 9, generator=gen) > 0.2
+    pm = torch.rand(7, 33, generator=gen) > 0.3
+    pm[4] = False
+    want, warg = O.maxsim_masked_argmax(Q, P, qm, pm)
+    out, arg = run(Q.numpy(), P.numpy(), qm.numpy(), pm.numpy(), want_arg=True)
+    np.testing.assert_allclose(out, want.numpy(), atol=2e-5)
+    assert np.array_equal(arg, warg.numpy())
+    assert np.all(out[:, 4] == 0.0)
