@@ -150,9 +150,15 @@ def main():
     def step():
         return retriever.search(Q, None, args.topk)
 
+    def barrier():
+        if args.backend == "nccl":
+            dist.barrier(device_ids=[dev_index])       # this rank's GPU, stated explicitly
+        else:
+            dist.barrier()
+
     def fence():
         if world > 1:
-            dist.barrier()
+            barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -226,7 +232,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
