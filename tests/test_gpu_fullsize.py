@@ -9,6 +9,9 @@ import torch
 
 from oracle import maxsim_oracle as O
 
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))      # golden_recipes
+
 pytestmark = pytest.mark.gpu
 
 LP, D, LQ = 1030, 128, 32
@@ -145,6 +148,20 @@ def test_rccl_exchange_single_rank(dev):
         assert torch.equal(s2, sc) and torch.equal(i2, ix)
         ms, mi = merge_candidates(s2, i2, 100)
         assert torch.equal(ms, sc)
+        dist.barrier(device_ids=[dev.index or 0])                        # the barrier form bench.py uses under nccl
+        # the training-side exchange (score columns) and one page-sharded fused step through RCCL
+        import golden_recipes as R
+        from evdr_amd import driver
+        from evdr_amd.utils.preprocess_data import l2_normalize
+        blk = torch.randn(8, 37, generator=g).to(dev)
+        assert torch.equal(driver.gather_columns(blk, (37,)), blk)
+        Qb, qmb, Pt, pmt, Pbar0, pms, hp = R.train_case("b4n8")
+        teacher = driver.TeacherScorer(l2_normalize(Pt * pmt.unsqueeze(-1)).to(dev), pmt.to(dev))
+        a = driver.FusedStudent(Pbar0.to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+        b = driver.FusedStudent(Pbar0.to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+        la = driver.sharded_fused_train_one_step(Qb, qmb, teacher, a, hp["temp"], (Pt.shape[0],))
+        lb = driver.fused_train_one_step(Qb, qmb, teacher, b, hp["temp"])
+        assert abs(la - lb) <= 1e-6 * abs(lb) and torch.allclose(a.x, b.x, atol=1e-6)
     finally:
         dist.destroy_process_group()
 
