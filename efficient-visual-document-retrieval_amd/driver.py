@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .corpus import PageCorpus
+from .corpus import PageCorpus, shard_range
 from .criterion import infonce_distillation_loss
 from .evaluator.metrics import results_from_topk
 from .evaluator.retrieval import CustomRetrievalEvaluator, score_multi_vector_masked
@@ -86,12 +86,17 @@ def train_one_step(Qb, qmb, teacher, pmask_teacher, Pbar_param, pmask_student, o
 
 @torch.no_grad()
 def eval_retrieval(evaluator: CustomRetrievalEvaluator, Q_test_norm, qmask_test, Pbar_param, pmask_student,
-                   relevant_docs_test, docidx_2_docid_test, qsidx_2_query_test, chunk_p: int = 64, k: int = 100):
-    """Retrieval metrics of the current student pages + "latency" (ms per query, synchronised)."""
+                   relevant_docs_test, docidx_2_docid_test, qsidx_2_query_test, chunk_p: int = 64, k: int = 100,
+                   shard_sizes=None):
+    """Retrieval metrics of the current student pages + "latency" (ms per query, synchronised).  With `shard_sizes`
+    (page-sharded run) Pbar_param / pmask_student are this rank's pages and the score columns are all-gathered: every rank
+    ends up with the same full score matrix and the same metrics."""
     P_now = l2_normalize(Pbar_param.detach() * pmask_student.unsqueeze(-1))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     scores = score_multi_vector_masked(Q_test_norm, P_now, qmask_test, pmask_student, chunk_p=chunk_p)
+    if shard_sizes is not None:
+        scores = gather_columns(scores, tuple(shard_sizes))
     ts, ti = ops.topk(scores, min(k, 128))
     torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t0) * 1000 / max(Q_test_norm.shape[0], 1)
@@ -106,7 +111,7 @@ def eval_retrieval(evaluator: CustomRetrievalEvaluator, Q_test_norm, qmask_test,
 
 @torch.no_grad()
 def evaluation_loss(Q_test_norm, qmask_test, teacher, pmask_teacher, Pbar_param, pmask_student, temp: float,
-                    chunk_p: int = 64) -> float:
+                    chunk_p: int = 64, shard_sizes=None) -> float:
     """InfoNCE-distillation loss on the test queries (mainv2_iter_distill_infonce.py:324-344)."""
     Psb = l2_normalize(Pbar_param * pmask_student.unsqueeze(-1))
     if isinstance(teacher, TeacherScorer):
@@ -114,6 +119,8 @@ def evaluation_loss(Q_test_norm, qmask_test, teacher, pmask_teacher, Pbar_param,
     else:
         sc_t = score_multi_vector_masked(Q_test_norm, teacher, qmask_test, pmask_teacher, chunk_p=chunk_p)
     sc_s = score_multi_vector_masked(Q_test_norm, Psb, qmask_test, pmask_student, chunk_p=chunk_p)
+    if shard_sizes is not None:
+        sc_t, sc_s = gather_columns(sc_t, tuple(shard_sizes)), gather_columns(sc_s, tuple(shard_sizes))
     return float(infonce_distillation_loss(sc_s, sc_t, temperature=temp).item())
 
 
@@ -180,8 +187,26 @@ def build_argparser():
     return p
 
 
+def _dist_context():
+    """(rank, world) of an initialised torch.distributed job, (0, 1) otherwise."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def gather_rows(block: torch.Tensor, sizes) -> torch.Tensor:
+    """This rank's pages (n_local, ...) -> all pages (N, ...) on every rank (checkpoints of a page-sharded run)."""
+    flat = block.reshape(block.shape[0], -1).t().contiguous()                       # (features, n_local): pages as columns
+    return gather_columns(flat.float(), tuple(sizes)).t().reshape((int(sum(sizes)),) + tuple(block.shape[1:])).to(block.dtype)
+
+
 def run(args) -> None:
+    """Single process: the reference's loop.  Under torch.distributed (WORLD_SIZE > 1, see main): PAGE-SHARDED -- every rank
+    holds the teacher and student pages [lo, hi) of its shard, the query batch is replicated, score columns are
+    all-gathered (training: `sharded_*_train_one_step`; evaluation: `shard_sizes`), rank 0 logs and checkpoints."""
     set_seed(args.seed)
+    rank, world = _dist_context()
     device = torch.device("cuda" if args.device == "auto" else args.device)
     mapping = json.loads(Path(args.mapping_json).read_text())
     for dataset in args.datasets:
@@ -196,6 +221,10 @@ def run(args) -> None:
         P_t_norm = l2_normalize(P_t_raw * pmask_t.unsqueeze(-1)).detach()
         n_pages = P_t_norm.shape[0]
         n_train = Q_train.shape[0]
+        lo, hi = shard_range(n_pages, rank, world)
+        shard_sizes = [shard_range(n_pages, r, world)[1] - shard_range(n_pages, r, world)[0] for r in range(world)] if world > 1 else None
+        if world > 1:
+            P_t_norm, pmask_t = P_t_norm[lo:hi].contiguous(), pmask_t[lo:hi].contiguous()
         teacher = TeacherScorer(P_t_norm, pmask_t, cache_size=n_train if args.cache_teacher_scores else 0)
         del P_t_raw
         steps_per_epoch = (n_train + args.q_batch - 1) // args.q_batch
@@ -215,6 +244,8 @@ def run(args) -> None:
             Pbar_raw, pmask_s, _ = preprocess_docs(Pbar_obj, attn_in, img_in, device)
             if Pbar_raw.shape[0] != n_pages:
                 raise ValueError(f"init doc count mismatch: got {Pbar_raw.shape[0]} vs teacher {n_pages}")
+            if world > 1:
+                Pbar_raw, pmask_s = Pbar_raw[lo:hi].contiguous(), pmask_s[lo:hi].contiguous()
             if args.fused_step:
                 if args.opt != "adamw":
                     raise ValueError("--fused_step implements AdamW only")
@@ -225,17 +256,24 @@ def run(args) -> None:
                 Pbar_param = nn.Parameter(Pbar_raw * pmask_s.unsqueeze(-1))
                 opt = set_optimizer(args.opt, Pbar_param, args.lr, args.weight_decay)
             out_dir = Path(args.out_root) / args.name / f"mf{mf}" / dataset
-            out_dir.mkdir(parents=True, exist_ok=True)
-            logger, tb = get_logger(out_dir)
-            cfg = out_dir / "config.json"
-            if not cfg.exists():
-                cfg.write_text(json.dumps({"dataset": dataset, "mf": mf, **vars(args)}, ensure_ascii=False, indent=2))
+            if rank == 0:
+                out_dir.mkdir(parents=True, exist_ok=True)
+                logger, tb = get_logger(out_dir)
+                cfg = out_dir / "config.json"
+                if not cfg.exists():
+                    cfg.write_text(json.dumps({"dataset": dataset, "mf": mf, **vars(args)}, ensure_ascii=False, indent=2))
+            else:                                                   # the other ranks compute the same numbers and stay silent
+                import logging
+                logger, tb = logging.getLogger(f"evdr.rank{rank}"), None
+                logger.addHandler(logging.NullHandler())
+                logger.propagate = False
             evaluator = CustomRetrievalEvaluator()
             ev_args = dict(evaluator=evaluator, Q_test_norm=Q_test, qmask_test=qmask_test, Pbar_param=Pbar_param,
                            pmask_student=pmask_s, relevant_docs_test=t_payload["relevant_docs"],
-                           docidx_2_docid_test=t_payload["docidx_2_docid"], qsidx_2_query_test=t_payload["qsidx_2_query"])
+                           docidx_2_docid_test=t_payload["docidx_2_docid"], qsidx_2_query_test=t_payload["qsidx_2_query"],
+                           shard_sizes=shard_sizes)
             el_args = dict(Q_test_norm=Q_test, qmask_test=qmask_test, teacher=teacher, pmask_teacher=pmask_t,
-                           Pbar_param=Pbar_param, pmask_student=pmask_s, temp=args.temp)
+                           Pbar_param=Pbar_param, pmask_student=pmask_s, temp=args.temp, shard_sizes=shard_sizes)
             metrics = eval_retrieval(**ev_args)
             log_eval(logger, tb, dataset=dataset, mf=mf, step=0, metrics=metrics, loss=evaluation_loss(**el_args))
             log_json(logger, {"dataset": dataset, "mf": mf, "step": 0, "note": "init Pbar before training"})
@@ -252,7 +290,13 @@ def run(args) -> None:
                 idx = perm[cursor:cursor + args.q_batch]
                 cursor += args.q_batch
                 qidx = idx if args.cache_teacher_scores else None
-                if student is not None:
+                if world > 1 and student is not None:
+                    loss_val = sharded_fused_train_one_step(Q_train[idx], qmask_train[idx], teacher, student, args.temp,
+                                                           shard_sizes, qidx=qidx)
+                elif world > 1:
+                    loss_val = sharded_train_one_step(Q_train[idx], qmask_train[idx], teacher, Pbar_param, pmask_s, opt,
+                                                     args.temp, shard_sizes)
+                elif student is not None:
                     loss_val = fused_train_one_step(Q_train[idx], qmask_train[idx], teacher, student, args.temp, qidx=qidx)
                 else:
                     loss_val = train_one_step(Q_train[idx], qmask_train[idx], teacher, pmask_t, Pbar_param, pmask_s, opt,
@@ -275,19 +319,47 @@ def run(args) -> None:
                         if upd:
                             logger.info(f"{tag} step| {step} | nDCG@5={best['NDCG@5']:.5f} | Recall@1={best['Recall@1']:.5f} "
                                         f"| Latency {metrics['latency']:.5f}")
-                            save_best_npz(out_dir=out_dir, fname=fname, dataset=dataset, mf=mf, step=step, best=best,
-                                          metrics=metrics, Pbar_param=Pbar_param, pmask_student=pmask_s, docid_tr=docid_tr,
-                                          doc_attn_in=attn_in, doc_img_in=img_in, args=args)
+                            P_all, pm_all = Pbar_param, pmask_s
+                            if world > 1:                           # every rank takes part in the gather, rank 0 writes
+                                P_all = gather_rows(Pbar_param.detach(), shard_sizes)
+                                pm_all = gather_rows(pmask_s.float(), shard_sizes) > 0.5
+                            if rank == 0:
+                                save_best_npz(out_dir=out_dir, fname=fname, dataset=dataset, mf=mf, step=step, best=best,
+                                              metrics=metrics, Pbar_param=P_all, pmask_student=pm_all, docid_tr=docid_tr,
+                                              doc_attn_in=attn_in, doc_img_in=img_in, args=args)
             log_json(logger, {"summary/latency": float(last.get("latency", 0.0)), "summary/best_recall": best_r1,
                               "summary/best_ndcg5": best_nd5, "note": "training finished"})
-            print(f"[done] {dataset} mf{mf} -> {out_dir}")
+            if rank == 0:
+                print(f"[done] {dataset} mf{mf} -> {out_dir}")
             if tb is not None:
                 tb.flush()
                 tb.close()
 
 
 def main(argv=None):
-    run(build_argparser().parse_args(argv))
+    """`python -m torch.distributed.run --nproc-per-node N ... driver.py ...` shards the pages over N GPUs (one process per
+    GPU, RCCL); without a launcher it is the single-process loop.  EVDR_DIST_BACKEND=gloo rehearses the exchange on one GPU."""
+    import os
+    import torch.distributed as dist
+    args = build_argparser().parse_args(argv)
+    started = False
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        backend = os.environ.get("EVDR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+        if args.device == "auto":
+            args.device = f"cuda:{local}"
+        started = True
+    try:
+        run(args)
+    finally:
+        if started:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -42,7 +42,8 @@ def _worker(rank, world, port, ret):
         # the same two steps on the fused kernels (no autograd graph): FusedStudent over this rank's pages
         student = driver.FusedStudent(Pbar0[lo:hi].to(dev), pms[lo:hi].to(dev), lr=hp["lr"], weight_decay=hp["wd"])
         flosses = [driver.sharded_fused_train_one_step(Qb, qmb, teacher, student, hp["temp"], sizes) for _ in range(2)]
-        ret[rank] = (losses, param.detach().cpu().numpy(), flosses, student.x.cpu().numpy())
+        rows = driver.gather_rows(student.x, sizes)                   # checkpoint path of the sharded driver: all pages on every rank
+        ret[rank] = (losses, param.detach().cpu().numpy(), flosses, student.x.cpu().numpy(), rows.cpu().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -73,4 +74,6 @@ def test_sharded_step_equals_single_device():
     for r in range(world):
         np.testing.assert_allclose(got[r][2], ref_losses, rtol=2e-6)           # fused sharded step: same losses ...
     fused = np.concatenate([got[r][3] for r in range(world)], axis=0)
+    for r in range(world):
+        assert np.array_equal(got[r][4], fused)                            # gather_rows: bit-exact reassembly on every rank
     np.testing.assert_allclose(fused, param.detach().cpu().numpy(), atol=2e-6)  # ... and the same parameters
