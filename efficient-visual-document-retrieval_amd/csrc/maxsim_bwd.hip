@@ -251,19 +251,23 @@ __global__ void __launch_bounds__(256) maxsim_bwd_q_kernel(const float* __restri
                                                           const uint8_t* __restrict__ qmask,
                                                           const uint32_t* __restrict__ pageflags,
                                                           const uint16_t* __restrict__ argmax, float* __restrict__ dQ,
-                                                          int nq, int lq, int np, int lp) {
+                                                          int nq, int lq, int np, int lp, int pages_per_seg) {
+    // blockIdx.y = page segment: with few (query, token) pairs (a training batch has 1024: 64 workgroups for 256 CUs) the
+    // page range is cut so that the grid fills the chip; the partial sums then meet in dQ (zeroed by the host) through
+    // global float atomics, 8 per lane and segment
     const int sub = threadIdx.x & 15;
     const int pair = blockIdx.x * 16 + (threadIdx.x >> 4);          // (q, n) handled by this 16-lane group
     if (pair >= nq * lq) return;
     const int q = pair / lq, n = pair - q * lq;
+    const int pbeg = blockIdx.y * pages_per_seg, pend = min(np, pbeg + pages_per_seg);
     f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
     const bool live = (qmask == nullptr) || qmask[pair] != 0;
     if (live) {
-        for (int p0 = 0; p0 < np; p0 += 16) {
+        for (int p0 = pbeg; p0 < pend; p0 += 16) {
             const int pl = p0 + sub;                                // this lane's page of the batch
             int a = 0;
             float w = 0.f;
-            if (pl < np) {
+            if (pl < pend) {
                 w = (pageflags[pl] & 1u) ? g[(int64_t)q * np + pl] : 0.f;       // has(p) = page has a valid patch
                 a = (int)argmax[((int64_t)q * np + pl) * lq + n];
             }
@@ -286,8 +290,17 @@ __global__ void __launch_bounds__(256) maxsim_bwd_q_kernel(const float* __restri
             }
         }
     }
-    *reinterpret_cast<f32x4*>(dQ + (int64_t)pair * EVDR_D + sub * 8) = s0;
-    *reinterpret_cast<f32x4*>(dQ + (int64_t)pair * EVDR_D + sub * 8 + 4) = s1;
+    float* dst = dQ + (int64_t)pair * EVDR_D + sub * 8;
+    if (gridDim.y == 1) {
+        *reinterpret_cast<f32x4*>(dst) = s0;
+        *reinterpret_cast<f32x4*>(dst + 4) = s1;
+    } else if (live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            atomicAdd(dst + i, s0[i]);
+            atomicAdd(dst + 4 + i, s1[i]);
+        }
+    }
 }
 
 // ---- l2_normalize (utils/preprocess_data.py:8-9) with an optional per-row mask, forward and backward ---------------
@@ -483,8 +496,20 @@ hipError_t evdr_launch_maxsim_bwd_q(const float* g, const float* P, const uint8_
                                     hipStream_t stream) {
     const int64_t pairs = nq * lq;
     if (pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(maxsim_bwd_q_kernel, dim3((unsigned)((pairs + 15) / 16)), dim3(256), 0, stream, g, P, qmask, pageflags,
-                       argmax, dQ, (int)nq, (int)lq, (int)np, (int)lp);
+    const int64_t bx = (pairs + 15) / 16;
+    int64_t nseg = (1024 + bx - 1) / bx;                            // ~1024 workgroups in total ...
+    const int64_t max_seg = (np + 63) / 64;                         // ... of at least 64 pages each
+    if (nseg > max_seg) nseg = max_seg;
+    if (nseg < 1) nseg = 1;
+    const int64_t per = ((np + nseg - 1) / nseg + 15) / 16 * 16;
+    nseg = per > 0 ? (np + per - 1) / per : 1;
+    if (nseg < 1) nseg = 1;
+    if (nseg > 1) {
+        hipError_t e = hipMemsetAsync(dQ, 0, (size_t)pairs * EVDR_D * sizeof(float), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(maxsim_bwd_q_kernel, dim3((unsigned)bx, (unsigned)nseg), dim3(256), 0, stream, g, P, qmask, pageflags,
+                       argmax, dQ, (int)nq, (int)lq, (int)np, (int)lp, (int)(per > 0 ? per : 16));
     return hipGetLastError();
 }
 
