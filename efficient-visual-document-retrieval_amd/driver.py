@@ -215,7 +215,10 @@ def run(args) -> None:
         t_payload = load_payload(f"{args.teacher_root}/{paths['split_before']}")
         docid_tr = t_payload["docid"]
         Q_train, qmask_train = preprocess_queries(q_payload["query"], q_payload["query_attnmask"], device="cpu")
-        Q_train, qmask_train = Q_train.pin_memory(), qmask_train.pin_memory()
+        if Q_train.numel() * 4 <= (8 << 30):        # the pseudo-queries (25 k x 32 x 128 fp32 = 0.4 GB) live in HBM: no H2D per step
+            Q_train, qmask_train = Q_train.to(device), qmask_train.to(device)
+        else:
+            Q_train, qmask_train = Q_train.pin_memory(), qmask_train.pin_memory()
         Q_test, qmask_test = preprocess_queries(t_payload["query"], t_payload["query_attnmask"], device=device)
         P_t_raw, pmask_t, _ = preprocess_docs(t_payload["documents"], t_payload["doc_attnmask"], t_payload["doc_imgmask"], device)
         P_t_norm = l2_normalize(P_t_raw * pmask_t.unsqueeze(-1)).detach()
