@@ -106,6 +106,47 @@ def cpu_baseline_leg(dev_corpus_slice: torch.Tensor, Qdev: torch.Tensor):
                       f"{dt:.2f} s, {cores} threads"}, s
 
 
+def self_launch(n: int, backend: str, need_gpus: bool = True) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this script, one per GPU, with the
+    rendezvous environment torch.distributed.run would give them, and wait.  This parent never touches the GPU (no HIP
+    call, no exec of a GPU-initialised process); rank 0's JSON line goes to the inherited stdout.  Returns the exit code."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()                     # counts devices without initialising the runtime
+    if need_gpus and backend == "nccl" and ndev < n:
+        print(f"bench.py: --gpus {n} with backend nccl needs {n} visible GPUs, found {ndev} "
+              f"(--backend gloo rehearses N>1 on fewer GPUs)", file=sys.stderr)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   EVDR_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for o in pending:                    # one rank failed: the others would wait in a collective forever
+                        procs[o].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,15 +158,32 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse N>1 on a 1-GPU box)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, form the process group, print its size and exit (launch check; no GPU work)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, args.backend, not args.rendezvous_only))   # plain `python bench.py --gpus N`: N fresh workers
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must equal --gpus")
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC for RCCL; before the first HIP call
+    launcher = os.environ.get("EVDR_BENCH_LAUNCHER", "torchrun" if "WORLD_SIZE" in os.environ else "none")
+    if args.rendezvous_only:
+        if world > 1:
+            dist.init_process_group("gloo")
+            seen = torch.ones(1)
+            dist.all_reduce(seen)
+            if rank == 0:
+                print(json.dumps({"rendezvous": "ok", "world_size": dist.get_world_size(), "ranks_seen": int(seen.item()),
+                                  "launcher": launcher}), flush=True)
+            dist.destroy_process_group()
+        else:
+            print(json.dumps({"rendezvous": "ok", "world_size": 1, "ranks_seen": 1, "launcher": launcher}), flush=True)
+        return
     dev_index = local_rank % max(torch.cuda.device_count(), 1)     # gloo rehearsal: several ranks may share a GPU
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -191,18 +249,29 @@ def main():
     k_ms = sum(a.elapsed_time(b) for a, b in ev) / reps
     flop_per_launch = args.queries * corpus.n_pages * FLOP_PER_PAIR
     achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
-    traffic = None
+    from evdr_amd import _lib as L
+    kernel_symbol = L.load().evdr_last_fwd_kernel().decode()        # the instance the launches above really dispatched
+    # HBM traffic: PMC counters cannot be read inside this process; `traffic` REPLAYS the figure of the committed
+    # rocprofv3 --pmc passes (profiles/hbm_traffic.json, made by scratch/pmc.sh) -- only when they were taken for this
+    # kernel instance and launch shape; the source file and its hash go into the line, null otherwise.
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            rec = json.load(open(tpath))
-            if rec.get("queries") == args.queries and rec.get("pages_per_gpu") == corpus.n_pages:
+            import hashlib
+            raw = open(tpath, "rb").read()
+            rec = json.loads(raw)
+            if (rec.get("queries") == args.queries and rec.get("pages_per_gpu") == corpus.n_pages
+                    and rec.get("kernel") == kernel_symbol):
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_src = {"kind": "replayed rocprofv3 --pmc counters (not measured in this run)",
+                               "file": "profiles/hbm_traffic.json", "sha256": hashlib.sha256(raw).hexdigest()[:16],
+                               "round": rec.get("round")}
         except Exception:
-            traffic = None
+            traffic, traffic_src = None, None
     roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                "kernel": "maxsim_fwd16s_kernel<QW=4,NPL=1,ARGMAX=0,ST=8,NSTAGE=2,BAL>", "kernel_ms": k_ms,
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": kernel_symbol, "kernel_ms": k_ms,
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "algorithmic_bytes_per_launch": corpus.n_pages * LP * D * 2}
 
@@ -228,6 +297,9 @@ def main():
                        "pages": args.pages, "patches_per_page": LP, "dim": D, "queries_per_step": args.queries,
                        "query_tokens": LQ, "topk": args.topk, "parallelism": f"page-shard x{world}"},
             "queries_per_sec": args.queries / (ms_per_step * 1e-3), "ndcg_at_5": ndcg5,
+            "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
+                     "backend": dist.get_backend() if world > 1 else None, "launcher": launcher,
+                     "exchange": "all_gather_into_tensor of (nq, 2k) int32 per rank" if world > 1 else None},
             "roofline": roofline, "cpu_baseline": cpu_base,
         }
         print(json.dumps(line), flush=True)

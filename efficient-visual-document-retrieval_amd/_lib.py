@@ -40,6 +40,9 @@ SIGNATURES = {
     "evdr_maxsim_topk": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64, _vp, _vp, _i32, C.c_int,
                                    _vp, _vp, _vp, _sz, _vp]),
     "evdr_infonce_distill_fwd_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
+    "evdr_debug_set_fwd_variant": (C.c_int, [C.c_int]),
+    "evdr_debug_set_pages_per_block": (C.c_int, [C.c_int]),
+    "evdr_last_fwd_kernel": (C.c_char_p, []),
 }
 
 
@@ -49,7 +52,7 @@ class EvdrError(RuntimeError):
         self.code = code
 
 
-ABI_VERSION = 201                  # EVDR_VERSION_NUM of csrc/evdr_common.h these signatures belong to
+ABI_VERSION = 300                  # EVDR_VERSION_NUM of csrc/evdr_common.h these signatures belong to
 
 _lib: Optional[C.CDLL] = None
 

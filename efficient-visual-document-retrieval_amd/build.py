@@ -35,20 +35,25 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every HIP source for gfx950 and link libevdr.so; returns its path."""
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = True, experiment: bool = False) -> str:
+    """Compile every HIP source for gfx950 and link libevdr.so; returns its path.  experiment=True builds
+    libevdr_exp.so with -DEVDR_EXPERIMENT instead (the stamped diagnostic kernel instances used by scratch/; never
+    loaded by the package)."""
+    obj_dir = OBJ_DIR + ("_exp" if experiment else "")
+    lib_path = LIB_PATH.replace("libevdr.so", "libevdr_exp.so") if experiment else LIB_PATH
+    flags = FLAGS + (["-DEVDR_EXPERIMENT"] if experiment else [])
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if force or _stale(obj, [sp] + HEADERS):
             jobs.append((sp, obj))
 
     def compile_one(job):
         sp, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+        cmd = [hipcc] + flags + ["-c", sp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}")
@@ -59,16 +64,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
-    objs = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(lib_path, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
-            print(f"[evdr build] linked {LIB_PATH}", file=sys.stderr)
-    return LIB_PATH
+            print(f"[evdr build] linked {lib_path}", file=sys.stderr)
+    return lib_path
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, experiment="--experiment" in sys.argv)

@@ -111,6 +111,12 @@ int evdr_version(void) { return EVDR_VERSION_NUM; }
 
 const char* evdr_last_error(void) { return g_err; }
 
+int evdr_debug_set_fwd_variant(int variant) { return evdr_fwd_variant_exchange(variant); }
+
+int evdr_debug_set_pages_per_block(int pages) { return evdr_pages_per_block_exchange(pages < 0 ? 0 : pages); }
+
+const char* evdr_last_fwd_kernel(void) { return evdr_last_fwd_kernel_name(); }
+
 int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, uint32_t* tilemask, uint32_t* pageflags,
                     void* hip_stream) {
     if (int rc = check_common(0, 0, np, lp)) return rc;

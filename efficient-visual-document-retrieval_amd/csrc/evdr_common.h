@@ -6,7 +6,7 @@
 
 #include "../../include/evdr.h"
 
-#define EVDR_VERSION_NUM 201   /* 0.2.1: fp16 hi/lo planes + absmax words, l2norm_fwd_split, adamw_advance, top-k workspace, qlist scratch */
+#define EVDR_VERSION_NUM 300   /* 0.3.0: debug hooks instead of environment switches, evdr_last_fwd_kernel */
 
 #define EVDR_D 128              /* embedding width the kernels are specialised for */
 #define EVDR_TILE_PATCHES 32    /* patches per LDS tile (two 16-row MFMA halves) */
@@ -91,6 +91,13 @@ static inline hipError_t evdr_ensure_dyn_lds(const void* kern, int bytes, uint64
     if (e == hipSuccess) devs_done |= bit;
     return e;
 }
+
+// debug hooks (maxsim_fwd.hip): forced kernel variant, pages-per-workgroup override, name of the last dispatched instance
+int evdr_fwd_variant_exchange(int v);
+int evdr_pages_per_block_exchange(int v);
+int evdr_pages_per_block_override();
+void evdr_note_fwd_kernel(const char* name);
+const char* evdr_last_fwd_kernel_name();
 
 // launches (defined in the .hip files; all enqueue on `stream` and return the launch status)
 hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& p, int nplanes, bool want_argmax, hipStream_t stream);

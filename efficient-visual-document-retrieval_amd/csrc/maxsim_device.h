@@ -1,7 +1,5 @@
 // Device-side helpers shared by the MaxSim forward kernels (maxsim_fwd.hip, maxsim_fwd16.hip).
 #pragma once
-#include <stdlib.h>
-
 #include "evdr_common.h"
 
 namespace evdr {
@@ -112,10 +110,8 @@ static inline int64_t evdr_set_geometry(EvdrFwdParams& p, int queries_per_wg) {
     p.ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     p.n_qgroups = (p.nq + queries_per_wg - 1) / queries_per_wg;
     p.pages_per_block = evdr_pages_per_block(p.np, p.n_qgroups, p.ntiles);
-    if (const char* e = getenv("EVDR_PPB")) {                       // experiment switch: pages per workgroup
-        const int v = atoi(e);
-        if (v > 0) p.pages_per_block = v < p.np ? v : p.np;
-    }
+    if (const int v = evdr_pages_per_block_override(); v > 0)       // evdr_debug_set_pages_per_block (A/B experiments)
+        p.pages_per_block = v < p.np ? v : p.np;
     p.n_chunks = (p.np + p.pages_per_block - 1) / p.pages_per_block;
     return (int64_t)((p.n_chunks + 7) / 8) * 8 * p.n_qgroups;     // grid size (whole groups of 8 for the XCD map)
 }

@@ -14,9 +14,20 @@
 //     served by that XCD's L2;
 //   * fp32 inputs are scored to fp32 accuracy as three products of fp16 hi/lo planes (nplanes = 2).
 // This file: the choice of queries-per-wave and kernel family for a launch.
-#include <stdlib.h>
+#include <atomic>
 
 #include "maxsim_device.h"
+
+// Test / experiment hooks (include/evdr.h "debug hooks"): process-wide, set explicitly through the C ABI.  The library
+// reads no environment variable.
+static std::atomic<int> g_fwd_variant{0};
+static std::atomic<int> g_pages_per_block{0};
+static thread_local const char* g_last_fwd_kernel = "";
+int evdr_fwd_variant_exchange(int v) { return g_fwd_variant.exchange(v); }
+int evdr_pages_per_block_exchange(int v) { return g_pages_per_block.exchange(v); }
+int evdr_pages_per_block_override() { return g_pages_per_block.load(std::memory_order_relaxed); }
+void evdr_note_fwd_kernel(const char* name) { g_last_fwd_kernel = name; }
+const char* evdr_last_fwd_kernel_name() { return g_last_fwd_kernel; }
 
 hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool want_argmax, hipStream_t stream) {
     EvdrFwdParams p = pin;
@@ -26,9 +37,7 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
     int qw;
     if (nplanes == 1 && !want_argmax) qw = (p.nq > 16) ? 4 : (p.nq > 8 ? 2 : 1);
     else qw = (p.nq > 8) ? 2 : 1;
-    // EVDR_FWD_VARIANT is an experiment switch read per launch (0/unset = default; see evdr_launch_maxsim_fwd16)
-    const char* e = getenv("EVDR_FWD_VARIANT");
-    const int variant = e ? atoi(e) : 0;
+    const int variant = g_fwd_variant.load(std::memory_order_relaxed);   // 0 = default dispatch (evdr_debug_set_fwd_variant)
     // HBM-bound launches (a handful of queries) want the refill in flight as early as possible: +3 % at 1-4 queries;
     // everything else hides the refill's address work under MFMAs: +2..4 %
     p.inblock_refill = p.nq > 4 ? 1 : 0;

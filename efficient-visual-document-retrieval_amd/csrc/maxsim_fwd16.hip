@@ -10,7 +10,7 @@
 //   A[row c][k = 8g + j]   = patch (16u + c) of the tile, dims 32s + 8g + j      (u = 16-patch half, s = k-step)
 //   B[k = 8g + j][col c]   = token (16t + c) of the query, dims 32s + 8g + j      (t = token half)
 //   C/D[row 4g + reg][col c] -> lane holds, for token 16t + c, the patches 16u + 4g + reg, reg = 0..3
-#include <stdlib.h>
+#include <stdio.h>
 #include <type_traits>
 
 #include "maxsim_device.h"
@@ -781,6 +781,13 @@ hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     static uint64_t attr_devs = 0;
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, 8 * QW);
+    static const char* const name = [] {
+        static char buf[96];
+        snprintf(buf, sizeof(buf), "maxsim_fwd16s_kernel<%d,%d,%s,%d,%d,%s,%s,%d,%s>", QW, NPL, ARGMAX ? "true" : "false", ST, NSTAGE,
+                 DIAG ? "true" : "false", BAL ? "true" : "false", OCC, SPQ2 ? "true" : "false");
+        return (const char*)buf;
+    }();
+    evdr_note_fwd_kernel(name);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(8 * 64), LDS, stream, p);
     return hipGetLastError();
 }
@@ -793,6 +800,12 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
     static uint64_t attr_devs = 0;
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, WAVES * QW);
+    static const char* const name = [] {
+        static char buf[64];
+        snprintf(buf, sizeof(buf), "maxsim_fwd16_kernel<%d,%d,%d,%d>", QW, WAVES, ST, NSTAGE);
+        return (const char*)buf;
+    }();
+    evdr_note_fwd_kernel(name);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), LDS, stream, p);
     return hipGetLastError();
 }
@@ -801,9 +814,15 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
 
 // NPL = 1 without argmax (retrieval / eval): geom 0 (default) = page-aligned 8-tile stages with the self-balancing priority
 // schedule (maxsim_fwd16s_kernel) for pages of >= 8 tiles, the flat per-tile ring (maxsim_fwd16_kernel) for shorter
-// pages; geom 1 forces the flat kernel, geom 2 the staged kernel without the priority schedule (A/B experiments);
-// 50/51 are the stamped diagnostic builds.  Argmax and fp16 hi/lo planes (nplanes = 2): the staged kernel for every
+// pages; geom 1 forces the flat kernel, geom 2 the staged kernel without the priority schedule (evdr_debug_set_fwd_variant:
+// the test sweep runs every instance against the oracle); 50/51 are the stamped diagnostic instances of the experiment build.  Argmax and fp16 hi/lo planes (nplanes = 2): the staged kernel for every
 // page length.
+#ifdef EVDR_EXPERIMENT
+static unsigned long long* g_dbg_buffer = nullptr;
+unsigned long long* evdr_experiment_dbg_buffer() { return g_dbg_buffer; }
+extern "C" void evdr_experiment_set_dbg_buffer(void* dev_ptr) { g_dbg_buffer = (unsigned long long*)dev_ptr; }
+#endif
+
 hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes, bool want_argmax, int geom, hipStream_t stream) {
     const int ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     if (nplanes == 2) {
@@ -831,12 +850,15 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes,
         return launch16s<1, 2, false, 4, 2, false, true>(p, stream);
     }
     if (want_argmax) return qw == 2 ? launch16s<2, 1, true, 8, 2, false, true>(p, stream) : launch16s<1, 1, true, 8, 2, false, true>(p, stream);
-    if ((geom == 50 || geom == 51) && ntiles >= 8 && qw == 4) {   // diagnostic builds with in-kernel stamps (scratch/diag_stamps.py)
+#ifdef EVDR_EXPERIMENT
+    // stamped diagnostic instances (scratch/diag_stamps.py): compiled only into the experiment build (libevdr_exp.so), the
+    // stamp buffer comes in through evdr_experiment_set_dbg_buffer
+    if ((geom == 50 || geom == 51) && ntiles >= 8 && qw == 4) {
         EvdrFwdParams pd = p;
-        const char* e = getenv("EVDR_DBG_PTR");
-        pd.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr;
+        pd.dbg = evdr_experiment_dbg_buffer();
         return geom == 50 ? launch16s<4, 1, false, 8, 2, true, false>(pd, stream) : launch16s<4, 1, false, 8, 2, true, true>(pd, stream);
     }
+#endif
     if (geom == 2 && ntiles >= 8 && qw == 4) return launch16s<4, 1, false, 8, 2, false, false>(p, stream);   // A/B: no priority schedule
     if ((geom != 1 && ntiles >= 8) || p.per_token) {
         if (qw == 4) return launch16s<4, 1, false, 8, 2, false, true>(p, stream);

@@ -298,7 +298,7 @@ def run(args) -> None:
                                                            shard_sizes, qidx=qidx)
                 elif world > 1:
                     loss_val = sharded_train_one_step(Q_train[idx], qmask_train[idx], teacher, Pbar_param, pmask_s, opt,
-                                                     args.temp, shard_sizes)
+                                                     args.temp, shard_sizes, qidx=qidx)
                 elif student is not None:
                     loss_val = fused_train_one_step(Q_train[idx], qmask_train[idx], teacher, student, args.temp, qidx=qidx)
                 else:
@@ -337,36 +337,6 @@ def run(args) -> None:
             if tb is not None:
                 tb.flush()
                 tb.close()
-
-
-def main(argv=None):
-    """`python -m torch.distributed.run --nproc-per-node N ... driver.py ...` shards the pages over N GPUs (one process per
-    GPU, RCCL); without a launcher it is the single-process loop.  EVDR_DIST_BACKEND=gloo rehearses the exchange on one GPU."""
-    import os
-    import torch.distributed as dist
-    args = build_argparser().parse_args(argv)
-    started = False
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local)
-        backend = os.environ.get("EVDR_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-        if args.device == "auto":
-            args.device = f"cuda:{local}"
-        started = True
-    try:
-        run(args)
-    finally:
-        if started:
-            dist.destroy_process_group()
-
-
-if __name__ == "__main__":
-    main()
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -540,7 +510,7 @@ def sharded_fused_train_one_step(Qb, qmb, teacher_shard: "TeacherScorer", studen
 
 
 def sharded_train_one_step(Qb, qmb, teacher_shard, Pbar_shard, pmask_student_shard, opt, temp: float,
-                           shard_sizes, group=None) -> float:
+                           shard_sizes, group=None, qidx: Optional[torch.Tensor] = None) -> float:
     """One InfoNCE-distillation update with the pages sharded over the ranks of `group`.
 
     Every rank holds the SAME query batch, its own slice of the teacher pages (`teacher_shard`: a TeacherScorer over
@@ -552,10 +522,40 @@ def sharded_train_one_step(Qb, qmb, teacher_shard, Pbar_shard, pmask_student_sha
     Qb = Qb.to(device, non_blocking=True)
     qmb = qmb.to(device, non_blocking=True)
     Psb = normalize_masked(Pbar_shard, pmask_student_shard)
-    sc_t = _GatherColumns.apply(teacher_shard.scores(Qb, qmb), tuple(shard_sizes), group)
+    sc_t = _GatherColumns.apply(teacher_shard.scores(Qb, qmb, qidx), tuple(shard_sizes), group)
     sc_s = _GatherColumns.apply(score_multi_vector_masked(Qb, Psb, qmb, pmask_student_shard), tuple(shard_sizes), group)
     loss = infonce_distillation_loss(sc_s, sc_t, temperature=temp)
     opt.zero_grad(set_to_none=True)
     loss.backward()
     opt.step()
     return float(loss.item())
+
+
+def main(argv=None):
+    """`python -m torch.distributed.run --nproc-per-node N ... driver.py ...` shards the pages over N GPUs (one process per
+    GPU, RCCL); without a launcher it is the single-process loop.  EVDR_DIST_BACKEND=gloo rehearses the exchange on one GPU."""
+    import os
+    import torch.distributed as dist
+    args = build_argparser().parse_args(argv)
+    started = False
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        backend = os.environ.get("EVDR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+        if args.device == "auto":
+            args.device = f"cuda:{local}"
+        started = True
+    try:
+        run(args)
+    finally:
+        if started:
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,5 @@
 """fp32-input forward (fp16 hi/lo planes): accuracy vs fp64 and time, per EVDR_FWD_VARIANT."""
+import _hooks as H
 import os, sys, torch
 sys.path.insert(0, "."); import evdr_amd
 from evdr_amd import ops
@@ -15,7 +16,7 @@ for nq, np_, lp, am in [(32, 500, 1030, False), (32, 500, 206, True), (500, 6847
     mx, ix = sim.max(-1)
     want = (mx * pm[sub].any(-1)[None, :, None] * qm[:, None, :]).sum(-1)
     for v in variants:
-        os.environ["EVDR_FWD_VARIANT"] = str(v)
+        H.set_variant(v)
         out, arg = ops.maxsim_forward(Q, P, qm, pm, want_argmax=am)
         torch.cuda.synchronize()
         err = (out[:, sub].double() - want).abs().max().item()

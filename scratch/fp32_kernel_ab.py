@@ -1,4 +1,5 @@
 """Kernel-only time of the fp16 hi/lo forward on prepared planes (no split, no mask packing), per EVDR_FWD_VARIANT."""
+import _hooks as H
 import os, sys, torch
 sys.path.insert(0, "."); import evdr_amd
 from evdr_amd import ops, _lib as L
@@ -18,7 +19,7 @@ for nq, np_, lp, am in [(32, 500, 1030, False), (32, 500, 206, True), (32, 500, 
                                              lp * 128, np_ * lp * 128, L.ptr(qa), L.ptr(pa), None, st))
     line = f"nq={nq:4d} np={np_:5d} lp={lp:5d} argmax={int(am)}"
     for v in variants:
-        os.environ["EVDR_FWD_VARIANT"] = str(v)
+        H.set_variant(v)
         call(); torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20

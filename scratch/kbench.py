@@ -1,5 +1,6 @@
 """Interleaved A/B timing of forward-kernel variants in ONE process (cdna_hip_programming.md rule 24).
 usage: python scratch/kbench.py [pages] [variants comma list] [rounds]"""
+import _hooks as H
 import os, sys, time, torch
 sys.path.insert(0, "."); import evdr_amd
 from evdr_amd.corpus import PageCorpus
@@ -20,7 +21,7 @@ ref = None
 res = {v: [] for v in variants}
 for rnd in range(rounds + 1):
     for v in variants:
-        os.environ["EVDR_FWD_VARIANT"] = str(v)
+        H.set_variant(v)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); corpus.score(Q, None, out=out); b.record(); torch.cuda.synchronize()
         if rnd == 0:

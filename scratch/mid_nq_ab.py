@@ -1,4 +1,5 @@
 """A/B of forward variants at mid query counts (1..8 query groups per page chunk)."""
+import _hooks as H
 import os, sys, torch
 sys.path.insert(0, "."); import evdr_amd, bench as B
 from evdr_amd.corpus import PageCorpus
@@ -11,7 +12,7 @@ for nq in (32, 64, 128, 256, 1024):
     Q = Qall[:nq].contiguous(); out = torch.empty((nq, pages), dtype=torch.float32, device=dev)
     line = f"nq={nq:4d}"
     for v in variants:
-        os.environ["EVDR_FWD_VARIANT"] = str(v)
+        H.set_variant(v)
         corpus.score(Q, None, out=out); torch.cuda.synchronize()
         if nq not in ref: ref[nq] = out.clone()
         same = bool(torch.equal(ref[nq], out))

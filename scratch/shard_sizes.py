@@ -1,4 +1,5 @@
 """Per-rank efficiency of the headline kernel at the shard sizes of 1/2/4/8-GPU strong scaling (1024 queries)."""
+import _hooks as H
 import os, sys, torch
 sys.path.insert(0, "."); import evdr_amd, bench as B
 from evdr_amd.corpus import PageCorpus
@@ -10,7 +11,7 @@ for pages in (12500, 25000, 50000):
     out = torch.empty((1024, pages), dtype=torch.float32, device=dev)
     line = f"pages={pages:6d}"
     for ppb in sys.argv[1].split(","):
-        os.environ["EVDR_PPB"] = ppb
+        H.set_ppb(ppb or 0)
         corpus.score(Q, None, out=out); torch.cuda.synchronize()
         ts = []
         for _ in range(3):

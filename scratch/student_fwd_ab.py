@@ -1,4 +1,5 @@
 """Student-forward shape (fp32, argmax, 206 patches): 3-tile vs 4-tile stages, interleaved repeats to cancel clock drift."""
+import _hooks as H
 import os, sys, torch
 sys.path.insert(0, "."); import evdr_amd
 from evdr_amd import ops, _lib as L
@@ -16,7 +17,7 @@ for nq, np_, lp, am in [(32, 500, 206, True), (32, 500, 206, False), (500, 6847,
     tot = {"10": 0.0, "11": 0.0}; ref = None
     for rep in range(6):
         for v in ("10", "11"):
-            os.environ["EVDR_FWD_VARIANT"] = v
+            H.set_variant(v)
             for _ in range(20): call()
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,0 +1,56 @@
+"""bench.py's launch paths on the CPU: `python bench.py --gpus N` must start N fresh ranks by itself (the driver's
+scaling run may call it without torch.distributed.run), the torchrun form must keep working, and a launch that cannot
+work must fail fast with a message instead of producing nothing.  --rendezvous-only forms the process group (gloo) and
+reports what it saw; no GPU work."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "EVDR_BENCH_LAUNCHER")}
+    return env
+
+
+def _last_json(out: str):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out                      # exactly ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_self_launch_forms_world_of_n():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--rendezvous-only"], capture_output=True, text=True, timeout=300,
+                       env=_clean_env())
+    assert r.returncode == 0, r.stderr
+    rec = _last_json(r.stdout)
+    assert rec == {"rendezvous": "ok", "world_size": 3, "ranks_seen": 3, "launcher": "self"}
+
+
+def test_torchrun_form_still_works():
+    port = 29900 + os.getpid() % 90
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--rendezvous-only"],
+                       capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert r.returncode == 0, r.stderr
+    rec = _last_json(r.stdout)
+    assert rec["world_size"] == 2 and rec["ranks_seen"] == 2 and rec["launcher"] == "torchrun"
+
+
+def test_single_rank_needs_no_launcher():
+    r = subprocess.run([sys.executable, BENCH, "--rendezvous-only"], capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert r.returncode == 0 and _last_json(r.stdout)["world_size"] == 1
+
+
+def test_world_size_mismatch_and_missing_gpus_fail_loudly():
+    env = dict(_clean_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--rendezvous-only"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    import torch
+    if torch.cuda.device_count() < 8:
+        r = subprocess.run([sys.executable, BENCH, "--gpus", "8"], capture_output=True, text=True, timeout=300, env=_clean_env())
+        assert r.returncode == 2 and "visible GPUs" in r.stderr and r.stdout.strip() == ""

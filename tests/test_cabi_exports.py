@@ -33,7 +33,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.evdr_version() == 201
+    from evdr_amd import _lib
+    assert lib.evdr_version() == _lib.ABI_VERSION == 300
     assert isinstance(lib.evdr_last_error(), bytes)
 
 
@@ -78,3 +79,27 @@ def test_header_is_plain_c():
         r = subprocess.run([cc, std, "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", lang, header],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_product_library_reads_no_environment_and_has_no_experiment_code(lib):
+    """Experiment scaffolding lives in the -DEVDR_EXPERIMENT build only: the shipped library neither imports getenv nor
+    exports the diagnostic hooks, and no DIAG (stamped) kernel instance is linked into it."""
+    import subprocess
+    from evdr_amd import _lib
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    exp = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "experiment" not in exp
+    # kernel symbols (host stubs) of the staged forward: template argument 6 is DIAG
+    stubs = [ln for ln in subprocess.run(["nm", "-C", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout.splitlines()
+             if "maxsim_fwd16s_kernel<" in ln]
+    assert stubs, "no forward kernel instances found"
+    for ln in stubs:
+        targs = ln[ln.index("maxsim_fwd16s_kernel<") + len("maxsim_fwd16s_kernel<"):].split(">")[0].split(",")
+        assert targs[5].strip() == "false", ln
+
+
+def test_debug_hooks_round_trip(lib):
+    assert lib.evdr_debug_set_fwd_variant(2) == 0 and lib.evdr_debug_set_fwd_variant(0) == 2
+    assert lib.evdr_debug_set_pages_per_block(7) == 0 and lib.evdr_debug_set_pages_per_block(0) == 7
+    assert lib.evdr_last_fwd_kernel() == b""            # nothing dispatched on this thread yet

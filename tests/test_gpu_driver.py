@@ -248,3 +248,46 @@ def test_driver_page_sharded_two_ranks(tmp_path):
         assert list(za["docid"]) == list(zb["docid"]) and int(za["meta"].item()["step"]) == int(zb["meta"].item()["step"])
         for da, db in zip(za["documents"], zb["documents"]):
             np.testing.assert_allclose(db, da, atol=5e-6)
+
+
+def _driver_cli(tmp_path, out, extra):
+    return ["--datasets", "synth", "--mapping_json", str(tmp_path / "map.json"), "--query_root", str(tmp_path),
+            "--teacher_root", str(tmp_path), "--init_root", str(tmp_path), "--mfs", "4", "--name", "run", "--max_steps", "6",
+            "--eval_every", "3", "--print_every", "1", "--q_batch", "32", "--out_root", str(out)] + extra
+
+
+def _losses(d):
+    lines = (d / "run" / "mf4" / "synth" / "train.log").read_text().splitlines()
+    return [json.loads(ln[ln.index("{"):])["train/loss"] for ln in lines if '"train/loss"' in ln]
+
+
+def test_driver_runs_as_a_program(tmp_path):
+    """`python -m evdr_amd.driver ...` as a FRESH child process (the documented launch), not
+    `driver.main([...])` from an importing test: every name main() needs must exist when the module runs as __main__.
+    Once single-process with --fused_step, once as two ranks (gloo exchange, both on this GPU) without and with it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    write_synthetic_dataset(tmp_path)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    single = tmp_path / "r_single"
+    r = subprocess.run([sys.executable, "-m", "evdr_amd.driver"] + _driver_cli(tmp_path, single, ["--fused_step", "--cache_teacher_scores"]),
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = _losses(single)
+    assert len(ref) == 6 and all(np.isfinite(ref))
+    port = 29700 + os.getpid() % 90
+    for tag, extra in (("fused", ["--fused_step", "--cache_teacher_scores"]), ("autograd", ["--cache_teacher_scores"])):
+        out = tmp_path / f"r_two_{tag}"
+        procs = []
+        for rank in range(2):
+            e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                     EVDR_DIST_BACKEND="gloo")
+            procs.append(subprocess.Popen([sys.executable, "-m", "evdr_amd.driver"] + _driver_cli(tmp_path, out, extra),
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e, cwd=root))
+        outs = [p.communicate(timeout=600) for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
+        np.testing.assert_allclose(_losses(out), ref, rtol=5e-5)
+        port += 1

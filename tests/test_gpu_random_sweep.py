@@ -1,8 +1,6 @@
 """Seeded random sweep over shapes, masks and dtypes: every forward kernel variant (staged for long pages, flat for short
 pages, staged without the priority schedule, fp16 hi/lo planes for fp32 inputs, argmax) against the oracle; argmax and dP
 against the oracle too."""
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -40,16 +38,18 @@ def _case(seed):
 def test_random_forward_all_kernels(seed):
     import evdr_amd  # noqa: F401
     import evdr_amd.ops as ops
+    from evdr_amd import _lib as L
     dev = torch.device("cuda:0")
     Q, P, qm, pm = _case(seed)
     want = O.maxsim_masked(Q.float(), P.float(), qm, pm)
     args = (qm.to(dev), pm.to(dev))
-    for variant in ("0", "1", "2"):                  # default, flat ring forced, staged without the priority schedule
-        os.environ["EVDR_FWD_VARIANT"] = variant
+    lib = L.load()
+    for variant in (0, 1, 2):                        # default, flat ring forced, staged without the priority schedule
+        lib.evdr_debug_set_fwd_variant(variant)      # explicit test hook (include/evdr.h): the library reads no environment
         try:
             got, _ = ops.maxsim_forward(Q.to(dev), P.to(dev), *args)
         finally:
-            os.environ.pop("EVDR_FWD_VARIANT", None)
+            lib.evdr_debug_set_fwd_variant(0)
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4, rtol=0, err_msg=f"variant {variant}")
     got32, _ = ops.maxsim_forward(Q.float().to(dev), P.float().to(dev), *args)          # fp16 hi/lo path
     np.testing.assert_allclose(got32.cpu().numpy(), want.numpy(), atol=1e-4, rtol=0)
