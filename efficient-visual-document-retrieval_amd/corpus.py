@@ -53,6 +53,7 @@ class PageCorpus:
         npg, lp, _ = P.shape
         planes, amax = (P.contiguous()[None], None) if P.dtype == torch.bfloat16 else ops.split_f32(P)
         tilemask, pageflags = ops.pack_pmask(pmask, npg, lp, dev)
+        ops.flag_nonfinite(planes[0], pmask, pageflags)          # once per corpus: NaN / Inf pages score NaN (evdr.h)
         return cls(planes, tilemask, pageflags, idx_base, amax)
 
     def shard(self, lo: int, hi: int) -> "PageCorpus":

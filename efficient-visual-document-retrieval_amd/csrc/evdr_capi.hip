@@ -54,6 +54,8 @@ int check_common(int64_t nq, int64_t lq, int64_t np, int64_t lp) {
     if (nq > INT32_MAX || np > INT32_MAX || lq > 65535 || lp > 65535)
         return fail(EVDR_ERR_SHAPE, "size out of range (nq=%lld lq=%lld np=%lld lp=%lld)", (long long)nq,
                     (long long)lq, (long long)np, (long long)lp);
+    if (nq * lq > INT32_MAX) return fail(EVDR_ERR_SHAPE, "nq * lq = %lld exceeds 2^31 - 1 (kernels index (query, token) pairs in 32 bits)",
+                                         (long long)(nq * lq));
     return EVDR_OK;
 }
 
@@ -135,6 +137,17 @@ int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* ama
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "split_f32 launch");
 }
 
+int evdr_flag_nonfinite(const void* P, int dtype, const uint8_t* pmask, int64_t np, int64_t lp, int64_t p_stride,
+                        uint32_t* pageflags, void* hip_stream) {
+    if (int rc = check_common(0, 0, np, lp)) return rc;
+    if (dtype != EVDR_F32 && dtype != EVDR_BF16 && dtype != EVDR_F16) return fail(EVDR_ERR_ARG, "dtype must be EVDR_F32, EVDR_BF16 or EVDR_F16");
+    if (np == 0 || lp == 0) return EVDR_OK;
+    if (!P || !pageflags) return fail(EVDR_ERR_ARG, "evdr_flag_nonfinite: null pointer");
+    if (p_stride < lp * EVDR_D) return fail(EVDR_ERR_ARG, "p_stride smaller than a page");
+    hipError_t e = evdr_launch_flag_nonfinite(P, dtype, pmask, np, lp, p_stride, pageflags, (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "flag_nonfinite launch");
+}
+
 size_t evdr_maxsim_fwd_workspace(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype) {
     if (nq < 0 || lq < 0 || np < 0 || lp < 0) return 0;
     return carve_fwd(nq, lq, np, lp, dtype).total;
@@ -162,6 +175,9 @@ int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const ui
     hipError_t e = evdr_launch_pack_pmask(pmask, np, lp, tilemask, pageflags, stream);
     if (e != hipSuccess) return hip_fail(e, "pack_pmask launch");
     if (dtype == EVDR_BF16) {
+        // NaN / Inf in a valid patch -> page flag bit 3 (one extra read of P; a resident corpus pays it once, evdr_flag_nonfinite)
+        if ((e = evdr_launch_flag_nonfinite(P, 1, pmask, np, lp, p_stride, pageflags, stream)) != hipSuccess)
+            return hip_fail(e, "flag_nonfinite launch");
         return run_fwd((const uint16_t*)Q, q_stride, 0, (const uint16_t*)P, p_stride, 0, qmask, tilemask, pageflags, out,
                        np, argmax_or_null, nq, lq, np, lp, 1, nullptr, nullptr, lq > 32 ? (int32_t*)(ws + w.qlist_off) : nullptr, stream);
     }
@@ -171,7 +187,8 @@ int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const ui
     uint16_t* ppl = (uint16_t*)(ws + w.pplanes_off);
     uint32_t* amax = (uint32_t*)(ws + w.amax_off);
     if ((e = evdr_launch_split_f32((const float*)Q, nq * lq, qpl, amax, stream)) != hipSuccess) return hip_fail(e, "split Q");
-    if ((e = evdr_launch_split_f32((const float*)P, np * lp, ppl, amax + 1, stream)) != hipSuccess) return hip_fail(e, "split P");
+    if ((e = evdr_launch_split_f32_pages((const float*)P, np * lp, ppl, amax + 1, pmask, lp, pageflags, stream)) != hipSuccess)
+        return hip_fail(e, "split P");
     return run_fwd(qpl, lq * EVDR_D, nq * lq * EVDR_D, ppl, lp * EVDR_D, np * lp * EVDR_D, qmask, tilemask, pageflags, out,
                    np, argmax_or_null, nq, lq, np, lp, 2, amax, amax + 1, lq > 32 ? (int32_t*)(ws + w.qlist_off) : nullptr, stream);
 }
@@ -203,9 +220,10 @@ int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const 
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd launch");
 }
 
-size_t evdr_maxsim_bwd_q_workspace(int64_t np, int64_t lp) {
-    if (np < 0 || lp < 0) return 0;
-    return align_up((size_t)np * ntiles_of(lp) * 4) + align_up((size_t)np * 4);
+size_t evdr_maxsim_bwd_q_workspace(int64_t nq, int64_t lq, int64_t np, int64_t lp) {
+    if (nq < 0 || lq < 0 || np < 0 || lp < 0) return 0;
+    return align_up((size_t)np * ntiles_of(lp) * 4) + align_up((size_t)np * 4) +
+           align_up((size_t)evdr_bwd_q_segments(nq * lq, np) * nq * lq * EVDR_D * sizeof(float));
 }
 
 int evdr_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
@@ -217,15 +235,16 @@ int evdr_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, cons
     if (!dQ) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_q: null dQ");
     if (np > 0 && (!g || !P || !argmax)) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_q: null g/P/argmax");
     if (np > 0 && lp == 0) return fail(EVDR_ERR_SHAPE, "lp == 0");
-    if (!workspace || workspace_bytes < evdr_maxsim_bwd_q_workspace(np, lp))
-        return fail(EVDR_ERR_WORKSPACE, "workspace too small: need %zu bytes", evdr_maxsim_bwd_q_workspace(np, lp));
+    if (!workspace || workspace_bytes < evdr_maxsim_bwd_q_workspace(nq, lq, np, lp))
+        return fail(EVDR_ERR_WORKSPACE, "workspace too small: need %zu bytes", evdr_maxsim_bwd_q_workspace(nq, lq, np, lp));
     hipStream_t stream = (hipStream_t)hip_stream;
     uint32_t* tilemask = (uint32_t*)workspace;
     uint32_t* pageflags = (uint32_t*)((char*)workspace + align_up((size_t)np * ntiles_of(lp) * 4));
     hipError_t e = hipSuccess;
     if (np > 0 && (e = evdr_launch_pack_pmask(pmask, np, lp, tilemask, pageflags, stream)) != hipSuccess)
         return hip_fail(e, "pack_pmask launch");
-    e = evdr_launch_maxsim_bwd_q(g, P, qmask, pageflags, argmax, dQ, nq, lq, np, lp, stream);
+    float* partials = (float*)((char*)workspace + align_up((size_t)np * ntiles_of(lp) * 4) + align_up((size_t)np * 4));
+    e = evdr_launch_maxsim_bwd_q(g, P, qmask, pageflags, argmax, dQ, partials, nq, lq, np, lp, stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd_q launch");
 }
 
@@ -259,19 +278,22 @@ int evdr_l2norm_fwd(const float* x, const uint8_t* rowmask_or_null, int64_t rows
     if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported", (long long)d);
     if (rows == 0) return EVDR_OK;
     if (!x || !y) return fail(EVDR_ERR_ARG, "evdr_l2norm_fwd: null pointer");
-    hipError_t e = evdr_launch_l2norm_fwd(x, rowmask_or_null, rows, eps, y, norm_or_null, nullptr, nullptr, (hipStream_t)hip_stream);
+    hipError_t e = evdr_launch_l2norm_fwd(x, rowmask_or_null, rows, eps, y, norm_or_null, nullptr, nullptr, nullptr, 1,
+                                          (hipStream_t)hip_stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "l2norm_fwd launch");
 }
 
 int evdr_l2norm_fwd_split(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps, float* y_or_null,
-                          float* norm_or_null, uint16_t* planes, uint32_t* amax_bits, void* hip_stream) {
+                          float* norm_or_null, uint16_t* planes, uint32_t* amax_bits, uint32_t* pageflags_or_null,
+                          int64_t rows_per_page, void* hip_stream) {
+    if (pageflags_or_null && rows_per_page < 1) return fail(EVDR_ERR_ARG, "evdr_l2norm_fwd_split: rows_per_page must be >= 1");
     if (rows < 0) return fail(EVDR_ERR_ARG, "negative rows");
     if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported", (long long)d);
     if (!amax_bits) return fail(EVDR_ERR_ARG, "evdr_l2norm_fwd_split: null amax_bits");
     if (rows == 0) return EVDR_OK;
     if (!x || !planes) return fail(EVDR_ERR_ARG, "evdr_l2norm_fwd_split: null pointer");
     hipError_t e = evdr_launch_l2norm_fwd(x, rowmask_or_null, rows, eps, y_or_null, norm_or_null, planes, amax_bits,
-                                          (hipStream_t)hip_stream);
+                                          pageflags_or_null, rows_per_page, (hipStream_t)hip_stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "l2norm_fwd_split launch");
 }
 

@@ -108,6 +108,10 @@ hipError_t evdr_launch_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, 
 hipError_t evdr_launch_build_qlist(const uint8_t* qmask, int64_t nq, int64_t lq, int64_t tok0, int32_t* qlist, int32_t* qcount,
                                    hipStream_t stream);
 hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, hipStream_t stream);
+hipError_t evdr_launch_split_f32_pages(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, const uint8_t* rowmask,
+                                       int64_t rows_per_page, uint32_t* pageflags, hipStream_t stream);
+hipError_t evdr_launch_flag_nonfinite(const void* P, int kind, const uint8_t* pmask, int64_t np, int64_t lp, int64_t p_stride,
+                                      uint32_t* pageflags, hipStream_t stream);
 hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                   const uint16_t* argmax, float* dP, int64_t nq, int64_t lq, int64_t np,
                                   int64_t lp, hipStream_t stream);
@@ -118,10 +122,12 @@ hipError_t evdr_launch_maxsim_bwd_adamw(const float* g, const float* Q, const ui
                                         hipStream_t stream);
 hipError_t evdr_launch_adamw_advance(void* state, float beta1, float beta2, hipStream_t stream);
 hipError_t evdr_launch_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint32_t* pageflags,
-                                    const uint16_t* argmax, float* dQ, int64_t nq, int64_t lq, int64_t np, int64_t lp,
-                                    hipStream_t stream);
+                                    const uint16_t* argmax, float* dQ, float* partials, int64_t nq, int64_t lq, int64_t np,
+                                    int64_t lp, hipStream_t stream);
+int evdr_bwd_q_segments(int64_t pairs, int64_t np);
 hipError_t evdr_launch_l2norm_fwd(const float* x, const uint8_t* rowmask, int64_t rows, float eps, float* y, float* norm,
-                                  uint16_t* planes, uint32_t* amax_bits, hipStream_t stream);
+                                  uint16_t* planes, uint32_t* amax_bits, uint32_t* pageflags, int64_t rows_per_page,
+                                  hipStream_t stream);
 hipError_t evdr_launch_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask, const float* norm, int64_t rows,
                                   float eps, float* dx, hipStream_t stream);
 hipError_t evdr_launch_topk(const float* scores, const int32_t* idx_map, int64_t nq, int64_t n,

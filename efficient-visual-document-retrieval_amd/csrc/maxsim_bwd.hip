@@ -253,8 +253,9 @@ __global__ void __launch_bounds__(256) maxsim_bwd_q_kernel(const float* __restri
                                                           const uint16_t* __restrict__ argmax, float* __restrict__ dQ,
                                                           int nq, int lq, int np, int lp, int pages_per_seg) {
     // blockIdx.y = page segment: with few (query, token) pairs (a training batch has 1024: 64 workgroups for 256 CUs) the
-    // page range is cut so that the grid fills the chip; the partial sums then meet in dQ (zeroed by the host) through
-    // global float atomics, 8 per lane and segment
+    // page range is cut so that the grid fills the chip; each segment writes its partial sums to its own slab of the
+    // workspace and reduce_segments_kernel adds the slabs in segment order: dQ is the same bits run after run (global
+    // float atomics, the first version, were not)
     const int sub = threadIdx.x & 15;
     const int pair = blockIdx.x * 16 + (threadIdx.x >> 4);          // (q, n) handled by this 16-lane group
     if (pair >= nq * lq) return;
@@ -290,16 +291,18 @@ __global__ void __launch_bounds__(256) maxsim_bwd_q_kernel(const float* __restri
             }
         }
     }
-    float* dst = dQ + (int64_t)pair * EVDR_D + sub * 8;
-    if (gridDim.y == 1) {
-        *reinterpret_cast<f32x4*>(dst) = s0;
-        *reinterpret_cast<f32x4*>(dst + 4) = s1;
-    } else if (live) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            atomicAdd(dst + i, s0[i]);
-            atomicAdd(dst + 4 + i, s1[i]);
-        }
+    float* dst = dQ + ((int64_t)blockIdx.y * nq * lq + pair) * EVDR_D + sub * 8;     // dQ = the partial slabs when gridDim.y > 1
+    *reinterpret_cast<f32x4*>(dst) = s0;
+    *reinterpret_cast<f32x4*>(dst + 4) = s1;
+}
+
+// out[i] = partials[0][i] + partials[1][i] + ... in that order (n4 float4 per slab)
+__global__ void __launch_bounds__(256) reduce_segments_kernel(const float* __restrict__ partials, int nseg, int64_t n4,
+                                                             float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 acc = reinterpret_cast<const f32x4*>(partials)[i];
+        for (int sgm = 1; sgm < nseg; ++sgm) acc += reinterpret_cast<const f32x4*>(partials)[(int64_t)sgm * n4 + i];
+        reinterpret_cast<f32x4*>(out)[i] = acc;
     }
 }
 
@@ -313,7 +316,8 @@ template <bool SPLIT>
 __global__ void __launch_bounds__(256) l2norm_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ rowmask,
                                                         int64_t rows, float eps, float* __restrict__ y,
                                                         float* __restrict__ norm, _Float16* __restrict__ hi,
-                                                        _Float16* __restrict__ lo, uint32_t* __restrict__ amax_bits) {
+                                                        _Float16* __restrict__ lo, uint32_t* __restrict__ amax_bits,
+                                                        uint32_t* __restrict__ pageflags, int64_t rows_per_page) {
     typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
     const int sub = threadIdx.x & 15;
     if (SPLIT && blockIdx.x == 0 && threadIdx.x == 0) *amax_bits = 0x3F800000u;
@@ -321,6 +325,17 @@ __global__ void __launch_bounds__(256) l2norm_fwd_kernel(const float* __restrict
         const float m = (rowmask == nullptr || rowmask[r] != 0) ? 1.f : 0.f;
         f32x4 v0 = *reinterpret_cast<const f32x4*>(x + r * EVDR_D + sub * 8);
         f32x4 v1 = *reinterpret_cast<const f32x4*>(x + r * EVDR_D + sub * 8 + 4);
+        if (pageflags != nullptr && m != 0.f) {
+            // a NaN / Inf element of an unmasked row (tested on the LOADED bits: the build lets the optimiser assume that
+            // float arithmetic never yields NaN): the normalised row is NaN as in the reference's x / (norm + eps), and the
+            // page is reported so that the scorer returns NaN for it (evdr.h, "non-finite inputs")
+            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+            const u32x4 b0 = __builtin_bit_cast(u32x4, v0), b1 = __builtin_bit_cast(u32x4, v1);
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= ((b0[k] & 0x7F800000u) == 0x7F800000u) || ((b1[k] & 0x7F800000u) == 0x7F800000u);
+            if (bad) atomicOr(&pageflags[r / rows_per_page], 8u);
+        }
         v0 *= m;
         v1 *= m;
         float ss = v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3] + v1[0] * v1[0] + v1[1] * v1[1] +
@@ -375,6 +390,14 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(const float* __restrict
 }
 
 // ---- infonce_distillation_loss (criterion.py:56-68) and d loss / d score_s, one workgroup per query row
+// order key of a float for arg-max purposes: larger key = larger value, -0.0 == +0.0, every NaN = the greatest key.  Key 0
+// is below every real value (-inf maps to 0x007FFFFF + 1 ... > 0), so "no element seen" never wins.
+__device__ __forceinline__ uint32_t nan_max_key(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;      // NaN (integer test: the build assumes no NaNs in float compares)
+    if (u == 0x80000000u) u = 0u;                                 // -0.0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
@@ -388,29 +411,34 @@ __global__ void __launch_bounds__(256) infonce_row_kernel(const float* __restric
                                                          int64_t n, float temp, float inv_tb,
                                                          float* __restrict__ row_loss, float* __restrict__ dscore) {
     __shared__ float red[4];
+    __shared__ uint32_t redk[4];
     __shared__ int redi[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* s = ss + (int64_t)blockIdx.x * n;
     const float* t = st + (int64_t)blockIdx.x * n;
-    // teacher argmax (first maximal index) and student max
-    float tbest = -__builtin_inff(), smax = -__builtin_inff();
-    int tidx = 0x7FFFFFFF;
+    // teacher argmax as torch.argmax defines it (criterion.py:61): first maximal index, -0.0 == +0.0, and a NaN counts as
+    // the greatest value (first NaN wins) -- on order keys, so that an all -inf or all-NaN row still yields a VALID index
+    // (0 / the first NaN) instead of leaving a sentinel that would be used as an address below
+    uint32_t tbest = 0u;
+    float smax = -__builtin_inff();
+    int tidx = 0;
     for (int64_t i = tid; i < n; i += 256) {
-        const float tv = t[i];
-        if (tv > tbest) { tbest = tv; tidx = (int)i; }
+        const uint32_t tk = nan_max_key(t[i]);
+        if (tk > tbest) { tbest = tk; tidx = (int)i; }
         smax = fmaxf(smax, s[i] / temp);
     }
     for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(tbest, o);
+        const uint32_t ov = (uint32_t)__shfl_xor((int)tbest, o);
         const int oi = __shfl_xor(tidx, o);
         if (ov > tbest || (ov == tbest && oi < tidx)) { tbest = ov; tidx = oi; }
     }
     smax = wave_max(smax);
-    if (lane == 0) { red[wave] = tbest; redi[wave] = tidx; }
+    if (lane == 0) { redk[wave] = tbest; redi[wave] = tidx; }
     __syncthreads();
-    tbest = red[0]; tidx = redi[0];
+    tbest = redk[0]; tidx = redi[0];
     for (int w = 1; w < 4; ++w)
-        if (red[w] > tbest || (red[w] == tbest && redi[w] < tidx)) { tbest = red[w]; tidx = redi[w]; }
+        if (redk[w] > tbest || (redk[w] == tbest && redi[w] < tidx)) { tbest = redk[w]; tidx = redi[w]; }
+    if (tidx < 0 || tidx >= n) tidx = 0;          // threads that saw no element carry index 0 with key 0: never out of range
     __syncthreads();
     if (lane == 0) red[wave] = smax;
     __syncthreads();
@@ -491,39 +519,56 @@ hipError_t evdr_launch_adamw_advance(void* state, float beta1, float beta2, hipS
     return hipGetLastError();
 }
 
-hipError_t evdr_launch_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint32_t* pageflags,
-                                    const uint16_t* argmax, float* dQ, int64_t nq, int64_t lq, int64_t np, int64_t lp,
-                                    hipStream_t stream) {
-    const int64_t pairs = nq * lq;
-    if (pairs == 0) return hipSuccess;
+// page segments of the dQ kernel (1 = every (query, token) pair walks all pages itself)
+static void bwd_q_geometry(int64_t pairs, int64_t np, int64_t& nseg, int64_t& per) {
     const int64_t bx = (pairs + 15) / 16;
-    int64_t nseg = (1024 + bx - 1) / bx;                            // ~1024 workgroups in total ...
+    nseg = bx > 0 ? (1024 + bx - 1) / bx : 1;                       // ~1024 workgroups in total ...
     const int64_t max_seg = (np + 63) / 64;                         // ... of at least 64 pages each
     if (nseg > max_seg) nseg = max_seg;
     if (nseg < 1) nseg = 1;
-    const int64_t per = ((np + nseg - 1) / nseg + 15) / 16 * 16;
+    per = ((np + nseg - 1) / nseg + 15) / 16 * 16;
     nseg = per > 0 ? (np + per - 1) / per : 1;
     if (nseg < 1) nseg = 1;
-    if (nseg > 1) {
-        hipError_t e = hipMemsetAsync(dQ, 0, (size_t)pairs * EVDR_D * sizeof(float), stream);
-        if (e != hipSuccess) return e;
-    }
+    if (per < 16) per = 16;
+}
+int evdr_bwd_q_segments(int64_t pairs, int64_t np) {
+    int64_t nseg, per;
+    bwd_q_geometry(pairs, np, nseg, per);
+    return nseg > 1 ? (int)nseg : 0;                                // slabs of workspace needed
+}
+
+hipError_t evdr_launch_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint32_t* pageflags,
+                                    const uint16_t* argmax, float* dQ, float* partials, int64_t nq, int64_t lq, int64_t np,
+                                    int64_t lp, hipStream_t stream) {
+    const int64_t pairs = nq * lq;
+    if (pairs == 0) return hipSuccess;
+    int64_t nseg, per;
+    bwd_q_geometry(pairs, np, nseg, per);
+    const int64_t bx = (pairs + 15) / 16;
     hipLaunchKernelGGL(maxsim_bwd_q_kernel, dim3((unsigned)bx, (unsigned)nseg), dim3(256), 0, stream, g, P, qmask, pageflags,
-                       argmax, dQ, (int)nq, (int)lq, (int)np, (int)lp, (int)(per > 0 ? per : 16));
+                       argmax, nseg > 1 ? partials : dQ, (int)nq, (int)lq, (int)np, (int)lp, (int)per);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || nseg == 1) return e;
+    const int64_t n4 = pairs * (EVDR_D / 4);
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_segments_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)partials, (int)nseg, n4, dQ);
     return hipGetLastError();
 }
 
 hipError_t evdr_launch_l2norm_fwd(const float* x, const uint8_t* rowmask, int64_t rows, float eps, float* y, float* norm,
-                                  uint16_t* planes, uint32_t* amax_bits, hipStream_t stream) {
+                                  uint16_t* planes, uint32_t* amax_bits, uint32_t* pageflags, int64_t rows_per_page,
+                                  hipStream_t stream) {
+    if (rows_per_page < 1) rows_per_page = 1;
     if (rows == 0) return hipSuccess;
     int64_t blocks = (rows + 15) / 16;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (planes != nullptr)
         hipLaunchKernelGGL(l2norm_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, x, rowmask, rows, eps, y, norm,
-                           (_Float16*)planes, (_Float16*)planes + rows * EVDR_D, amax_bits);
+                           (_Float16*)planes, (_Float16*)planes + rows * EVDR_D, amax_bits, pageflags, rows_per_page);
     else
         hipLaunchKernelGGL(l2norm_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, x, rowmask, rows, eps, y, norm,
-                           (_Float16*)nullptr, (_Float16*)nullptr, (uint32_t*)nullptr);
+                           (_Float16*)nullptr, (_Float16*)nullptr, (uint32_t*)nullptr, pageflags, rows_per_page);
     return hipGetLastError();
 }
 

@@ -37,6 +37,37 @@ __device__ __forceinline__ void resolve_queries(const EvdrFwdParams& p, int q0, 
     }
 }
 
+
+// ---- non-finite inputs (include/evdr.h, "non-finite inputs") ------------------------------------------------------------
+// v_max3_f32 drops NaNs where torch.max propagates them (evaluator/retrieval.py:201), and the hot loop has no room for a
+// NaN-propagating max.  So non-finite INPUTS are detected instead -- pages at preparation time (page flag bit 3), queries
+// here, once per wave, on the resident fragments -- and the page epilogue returns NaN for every (query, page) pair that
+// involves one, which is where the reference's NaN lands: a NaN in a valid patch poisons its page's column, a NaN in ANY
+// token of a query (masked ones included: NaN * 0 = NaN, :207) poisons the row on every page that has a valid patch.
+// Exponent test on the 16-bit elements (bf16: 0x7F80, fp16: 0x7C00); all integer, the build assumes no NaNs in float compares.
+// Per 32-bit word holding two elements: (w & exponent fields) + (one unit of each field) carries into bit 15 / bit 31
+// exactly when a field is all ones; the words of a fragment are OR-ed and tested once (3 VALU per word).
+template <typename F>
+__device__ __forceinline__ uint32_t frag_exp_carry(const F& v) {
+    constexpr uint32_t M = std::is_same<F, bf16x8>::value ? 0x7F807F80u : 0x7C007C00u;
+    constexpr uint32_t U = std::is_same<F, bf16x8>::value ? 0x00800080u : 0x04000400u;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4v;
+    const u32x4v w = __builtin_bit_cast(u32x4v, v);
+    return ((w[0] & M) + U) | ((w[1] & M) + U) | ((w[2] & M) + U) | ((w[3] & M) + U);
+}
+// 32 token bits of one query of the wave (bit n = token n holds a non-finite element), wave-uniform
+__device__ __forceinline__ uint32_t token_bad_bits(bool bad_t0, bool bad_t1) {
+    const unsigned long long b0 = __ballot(bad_t0), b1 = __ballot(bad_t1);     // lane = 16 g + c holds token 16 t + c
+    const uint32_t f0 = (uint32_t)((b0 | (b0 >> 16) | (b0 >> 32) | (b0 >> 48)) & 0xFFFFull);
+    const uint32_t f1 = (uint32_t)((b1 | (b1 >> 16) | (b1 >> 32) | (b1 >> 48)) & 0xFFFFull);
+    return f0 | (f1 << 16);
+}
+__device__ __forceinline__ float opaque_nan() {
+    float v = __builtin_bit_cast(float, 0x7FC00000u);
+    asm volatile("" : "+v"(v));                        // the optimiser must not reason about it (-fno-honor-nans)
+    return v;
+}
+
 // Flat per-tile schedule: WAVES waves per workgroup, ST 32-patch tiles per ring stage, NSTAGE ring slots over the
 // block's flat tile stream (stages ignore page boundaries).  Used for short pages (< 8 tiles, e.g. the compressed
 // student pages); long pages take maxsim_fwd16s_kernel below.
@@ -85,6 +116,14 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t qbad[QW];                                    // wave-uniform: tokens of query j with a NaN / Inf element
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+        uint32_t c0 = 0u, c1 = 0u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { c0 |= frag_exp_carry(bq[j][0][s]); c1 |= frag_exp_carry(bq[j][1][s]); }
+        qbad[j] = token_bad_bits((c0 & 0x80008000u) != 0u, (c1 & 0x80008000u) != 0u);
+    }
     if (p.accumulate && p.argmax == nullptr) {
         // a later 32-token slice of long queries (queries padded to the longest of a set: most have no valid token here):
         // a wave whose queries add nothing skips its MFMA work, a workgroup without any such query leaves at once
@@ -229,6 +268,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
                                 cs += xgroup_max(run[j][t]) * has * qwt[j][t];
                             }
                             cs = row16_sum(cs);
+                            if ((pflags & 1u) && ((pflags & 8u) || qbad[j] != 0u)) cs = opaque_nan();
                             if (lane == 0 && qreal[j] >= 0) {
                                 float* o = p.out + (int64_t)qreal[j] * p.out_stride + page;
                                 if (p.accumulate) atomicAdd(o, cs);
@@ -369,6 +409,7 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
             qwt[j][t] = w;
         }
     }
+    uint32_t qbad[QW];                                    // wave-uniform: tokens of query j with a NaN / Inf element
     // fp16 planes carry x * 2^k: scores come back to real units with one exact power-of-two factor
     float inv = 1.f;
     if constexpr (NPL == 2) {
@@ -377,6 +418,13 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
         inv = __builtin_ldexpf(1.f, -(kq + kp));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {                        // plane 0 is the hi plane: NaN and Inf survive the split there
+        uint32_t c0 = 0u, c1 = 0u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { c0 |= frag_exp_carry(bq[j][0][0][s]); c1 |= frag_exp_carry(bq[j][0][1][s]); }
+        qbad[j] = token_bad_bits((c0 & 0x80008000u) != 0u, (c1 & 0x80008000u) != 0u);
+    }
     if (p.accumulate && p.argmax == nullptr) {          // later 32-token slice: see maxsim_fwd16_kernel
         float any = 0.f;
 #pragma unroll
@@ -742,7 +790,9 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                         // packed single-token queries: one score (and argmax) per token, no sum over the pack
                         const int64_t qrow = (int64_t)qreal[j] * 32 + tok;
                         if (g == 0 && qreal[j] >= 0 && qrow < p.per_token) {
-                            p.out[qrow * p.out_stride + page] = v * has * qwt[j][t];
+                            float o = v * has * qwt[j][t];
+                            if ((pflags & 1u) && ((pflags & 8u) || ((qbad[j] >> tok) & 1u))) o = opaque_nan();
+                            p.out[qrow * p.out_stride + page] = o;
                             if constexpr (ARGMAX) p.argmax[qrow * p.np + page] = (uint16_t)bi;
                         }
                         continue;
@@ -755,6 +805,7 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                 }
                 if (p.per_token) continue;
                 cs = row16_sum(cs);
+                if ((pflags & 1u) && ((pflags & 8u) || qbad[j] != 0u)) cs = opaque_nan();
                 if (lane == 0 && qreal[j] >= 0) {
                     float* o = p.out + (int64_t)qreal[j] * p.out_stride + page;
                     if (p.accumulate) atomicAdd(o, cs);

@@ -46,16 +46,26 @@ __global__ void __launch_bounds__(64) pack_pmask_kernel(const uint8_t* __restric
     }
 }
 
-// absmax of the tensor as raw bits (|x| as uint32 orders like the float; NaN sorts above inf and poisons the result,
-// as it would poison the reference's scores)
-__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n4, uint32_t* __restrict__ amax_bits) {
+// absmax over the FINITE elements of the tensor, as raw bits (|x| as uint32 orders like the float).  NaN / Inf elements do
+// not take part: one diverged row must not change the power-of-two scale of every other row.  They are reported instead:
+// with `pageflags` given (pages: rows_per_page = lp, rowmask = pmask), a non-finite element in a VALID row sets bit 3 of
+// its page's flag word, which makes the forward kernel return NaN for that page (include/evdr.h, "non-finite inputs").
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n4, uint32_t* __restrict__ amax_bits,
+                                                     const uint8_t* __restrict__ rowmask, int64_t rows_per_page,
+                                                     uint32_t* __restrict__ pageflags) {
     uint32_t m = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        bool bad = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float f = v[k];      // by value: __builtin_bit_cast on the vector-element lvalue reads element 0 (hipcc 7.2)
-            m = max(m, __builtin_bit_cast(uint32_t, f) & 0x7FFFFFFFu);
+            const uint32_t b = __builtin_bit_cast(uint32_t, f) & 0x7FFFFFFFu;
+            if (b < 0x7F800000u) m = max(m, b); else bad = true;
+        }
+        if (bad && pageflags != nullptr) {                       // rare path: which row / page was that?
+            const int64_t row = (i * 4) / EVDR_D;
+            if (rowmask == nullptr || rowmask[row] != 0) atomicOr(&pageflags[row / rows_per_page], 8u);
         }
     }
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
@@ -66,6 +76,36 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
     if (threadIdx.x == 0) {
         m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
         if (m != 0u) atomicMax(amax_bits, m);
+    }
+}
+
+// Non-finite scan of 16-bit pages (a bf16 corpus, or the hi plane of fp16 hi/lo planes) and of fp32 pages that are not
+// going through absmax_kernel: one 16-lane group per 128-wide row, 16 B (or 2 x 16 B) per lane; a NaN / Inf element in a
+// valid row sets bit 3 of the page's flag word.  EXP16: exponent mask of the element type (bf16 0x7F80, fp16 0x7C00).
+template <int KIND>    // 0 = fp32, 1 = bf16, 2 = fp16
+__global__ void __launch_bounds__(256) nonfinite_scan_kernel(const void* __restrict__ x, const uint8_t* __restrict__ pmask,
+                                                             int64_t np, int64_t lp, int64_t p_stride,
+                                                             uint32_t* __restrict__ pageflags) {
+    const int sub = threadIdx.x & 15;
+    const int64_t rows = np * lp;
+    for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < rows; r += (int64_t)gridDim.x * 16) {
+        const int64_t page = r / lp, patch = r - page * lp;
+        const int64_t off = page * p_stride + patch * EVDR_D + sub * 8;
+        bool bad = false;
+        if constexpr (KIND == 0) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(reinterpret_cast<const float*>(x) + off);
+            const uint4 a = *reinterpret_cast<const uint4*>(w), b = *reinterpret_cast<const uint4*>(w + 4);
+            const uint32_t e[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bad |= (e[k] & 0x7F800000u) == 0x7F800000u;
+        } else {
+            constexpr uint32_t M = (KIND == 1) ? 0x7F80u : 0x7C00u;
+            const uint4 a = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(x) + off);
+            const uint32_t e[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= ((e[k] & M) == M) || ((e[k] & (M << 16)) == (M << 16));
+        }
+        if (bad && (pmask == nullptr || pmask[r] != 0)) atomicOr(&pageflags[page], 8u);
     }
 }
 
@@ -133,14 +173,32 @@ hipError_t evdr_launch_build_qlist(const uint8_t* qmask, int64_t nq, int64_t lq,
     return hipGetLastError();
 }
 
+hipError_t evdr_launch_flag_nonfinite(const void* P, int kind, const uint8_t* pmask, int64_t np, int64_t lp, int64_t p_stride,
+                                      uint32_t* pageflags, hipStream_t stream) {
+    const int64_t rows = np * lp;
+    if (rows == 0) return hipSuccess;
+    int64_t blocks = (rows + 15) / 16;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    auto kern = kind == 0 ? nonfinite_scan_kernel<0> : (kind == 1 ? nonfinite_scan_kernel<1> : nonfinite_scan_kernel<2>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, P, pmask, np, lp, p_stride, pageflags);
+    return hipGetLastError();
+}
+
 hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, hipStream_t stream) {
+    return evdr_launch_split_f32_pages(x, rows, planes, amax_bits, nullptr, 1, nullptr, stream);
+}
+
+// the same for pages: non-finite elements of valid patches are reported in `pageflags` (bit 3) on the way
+hipError_t evdr_launch_split_f32_pages(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, const uint8_t* rowmask,
+                                       int64_t rows_per_page, uint32_t* pageflags, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const int64_t n8 = rows * (EVDR_D / 8);
     if (n8 == 0) return hipSuccess;
     int64_t blocks = (n8 + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;     // grid-stride beyond 8 blocks per CU
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream, x, n8 * 2, amax_bits);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream, x, n8 * 2, amax_bits,
+                       rowmask, rows_per_page, pageflags);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const int64_t plane = rows * EVDR_D;
     hipLaunchKernelGGL(split_h2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n8, amax_bits, (_Float16*)planes,

@@ -18,8 +18,10 @@ constexpr int TK_BINS = 2048;
 constexpr int TK_BPT = TK_BINS / TK_THREADS;     // histogram bins per thread in the suffix scan
 
 __device__ __forceinline__ uint32_t order_key(float f) {
-    f = f + 0.0f;                                    // -0.0 -> +0.0 so that equal scores tie
-    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;   // NaN of either sign: ranks first, like torch.topk (integer test:
+                                                                // the build assumes no NaNs in float compares)
+    if (u == 0x80000000u) u = 0u;                    // -0.0 -> +0.0 so that equal scores tie
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float key_to_float(uint32_t k) {

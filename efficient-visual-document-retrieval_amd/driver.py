@@ -97,13 +97,13 @@ def eval_retrieval(evaluator: CustomRetrievalEvaluator, Q_test_norm, qmask_test,
     scores = score_multi_vector_masked(Q_test_norm, P_now, qmask_test, pmask_student, chunk_p=chunk_p)
     if shard_sizes is not None:
         scores = gather_columns(scores, tuple(shard_sizes))
-    ts, ti = ops.topk(scores, min(k, 128))
+    ts, ti, tied = ops.topk_with_ties(scores, min(k, 128))     # ties cut at rank k: all tied candidates go to the metric
     torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t0) * 1000 / max(Q_test_norm.shape[0], 1)
     nq, n = scores.shape
     qkeys = [str(qsidx_2_query_test[i]) if qsidx_2_query_test is not None else str(i) for i in range(nq)]
     docids = [docidx_2_docid_test[str(j)] for j in range(n)]
-    results = results_from_topk(ts.cpu().numpy(), ti.cpu().numpy(), qkeys, docids)
+    results = results_from_topk(ts.cpu().numpy(), ti.cpu().numpy(), qkeys, docids, extra=tied)
     metrics = evaluator.compute_mteb_metrics(relevant_docs_test, results)
     metrics["latency"] = float(latency_ms)
     return metrics
@@ -365,7 +365,7 @@ class FusedStudent:
     def scores(self, Qb, qmb) -> Tuple[torch.Tensor, torch.Tensor]:
         """Student scores (B, n_pages) and the argmax the update needs.  l2_normalize(Pbar * pmask) lands directly in the
         scorer's fp16 hi/lo planes (no fp32 copy, no absmax/split pass)."""
-        pplanes, pamax = ops.l2norm_split(self.x, self.pmask, self.l2_eps)
+        pplanes, pamax = ops.l2norm_split(self.x, self.pmask, self.l2_eps, pageflags=self.pageflags)   # a diverged page scores NaN
         qplanes, qamax = ops.split_f32(Qb)
         return ops.maxsim_forward_prepared(qplanes, qamax, pplanes, pamax, qmb, self.tilemask, self.pageflags,
                                            want_argmax=True)

@@ -74,14 +74,22 @@ def evaluate(qrels: Dict[str, Dict[str, int]], results: Dict[str, Dict[str, floa
 
 
 def results_from_topk(top_scores: np.ndarray, top_idx: np.ndarray, query_keys: Sequence[str],
-                      docids: Sequence[str]) -> Dict[str, Dict[str, float]]:
+                      docids: Sequence[str], extra=None) -> Dict[str, Dict[str, float]]:
     """Device top-k lists -> the {qid: {docid: score}} dict the metric wrapper consumes.  Replaces the
-    reference's per-element `.item()` loop (mainv2_iter_distill_infonce.py:311-317) with two D2H copies."""
+    reference's per-element `.item()` loop (mainv2_iter_distill_infonce.py:311-317) with two D2H copies.
+    `extra` (ops.topk_with_ties): rows whose k-th score is tied beyond the device cut carry every column with a score >=
+    the k-th one, so that the docid-descending tie rule of trec_eval picks from the same candidates as the reference's
+    all-pairs dict does."""
     out: Dict[str, Dict[str, float]] = {}
     for qi, qk in enumerate(query_keys):
         row = {}
-        for s, i in zip(top_scores[qi].tolist(), top_idx[qi].tolist()):
-            if i >= 0:
+        if extra and qi in extra:
+            cols, sc = extra[qi]
+            for s, i in zip(sc.tolist(), cols.tolist()):
                 row[docids[i]] = float(s)
+        else:
+            for s, i in zip(top_scores[qi].tolist(), top_idx[qi].tolist()):
+                if i >= 0:
+                    row[docids[i]] = float(s)
         out[str(qk)] = row
     return out

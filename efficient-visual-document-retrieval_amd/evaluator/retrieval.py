@@ -64,6 +64,7 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
         return hit[2]
     planes, amax = ops.split_f32(P)
     tilemask, pageflags = ops.pack_pmask(pmask, P.shape[0], P.shape[1], P.device)
+    ops.flag_nonfinite(planes[0], pmask, pageflags)
     prep = (planes, amax, tilemask, pageflags)
     nbytes = planes.numel() * planes.element_size()
     if nbytes <= _PREPARED_MAX_BYTES:

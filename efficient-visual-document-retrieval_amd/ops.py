@@ -56,6 +56,24 @@ def pack_pmask(pmask: Optional[torch.Tensor], npages: int, lp: int, dev) -> Tupl
     return tilemask, pageflags
 
 
+def flag_nonfinite(P: torch.Tensor, pmask: Optional[torch.Tensor], pageflags: torch.Tensor) -> None:
+    """Set bit 3 of pageflags[p] for every page with a NaN / Inf element in a valid patch (evdr_flag_nonfinite): the
+    forward kernels then return NaN for that page, where torch.max would have propagated it (evaluator/retrieval.py:201).
+    P (np, lp, 128) fp32 / bf16 / fp16 (the hi plane of fp16 hi/lo planes), dense rows, any page stride."""
+    dev = _require_cuda(P, pageflags)
+    npg, lp, d = P.shape
+    if npg == 0 or lp == 0:
+        return
+    kind = {torch.float32: L.EVDR_F32, torch.bfloat16: L.EVDR_BF16, torch.float16: L.EVDR_F16}.get(P.dtype)
+    if kind is None or d != D or P.stride(2) != 1 or P.stride(1) != D:
+        raise RuntimeError("flag_nonfinite needs (np, lp, 128) fp32 / bf16 / fp16 pages with dense rows")
+    pm = _mask_u8(pmask, (npg, lp), dev)
+    lib = L.load()
+    with torch.cuda.device(dev):
+        L.check(lib.evdr_flag_nonfinite(L.ptr(P), kind, L.ptr(pm), npg, lp, int(P.stride(0)), L.ptr(pageflags),
+                                        L.current_stream_handle(dev)))
+
+
 def split_f32(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """(..., 128) fp32 -> ((2, ..., 128) fp16 planes hi/lo of x * 2^k, absmax word): hi + lo == x * 2^k to ~2^-22, with
     one power of two k per tensor that the kernels derive from the absmax word (int32 tensor of 1 element holding the
@@ -188,6 +206,28 @@ def topk(scores: torch.Tensor, k: int, idx_base: int = 0,
     return ts, ti
 
 
+def topk_with_ties(scores: torch.Tensor, k: int):
+    """`topk` plus what a ranking by another tie rule needs: for every row whose k-th score is shared by columns that did
+    NOT make the cut (score desc, index asc keeps the lowest indices), ALL columns with score >= the k-th score.
+
+    The reference hands every score to trec_eval (mainv2_iter_distill_infonce.py:311-317), which breaks ties by docid
+    DESCENDING; a device cut by index ascending would hand it a different candidate set whenever equal scores straddle
+    rank k.  With the extra columns the metric layer sees every candidate that can appear in ANY top-k under ANY tie
+    rule, so its result equals the all-pairs evaluation for every cut-off <= k.  Returns (top_scores, top_idx, extra) with
+    extra = {row: (column indices int64, their scores fp32)} as host numpy arrays -- empty when no tie is cut (the usual
+    case: one small device reduction and one sync, no further transfer)."""
+    ts, ti = topk(scores, k)
+    extra = {}
+    nq, n = scores.shape
+    if nq and n > k:
+        kth = ts[:, k - 1:k]
+        cut = ((scores >= kth).sum(dim=1) > k).nonzero().flatten().tolist()        # NaN rows compare false: left as they are
+        for r in cut:
+            cols = (scores[r] >= kth[r]).nonzero().flatten()
+            extra[int(r)] = (cols.cpu().numpy(), scores[r, cols].float().cpu().numpy())
+    return ts, ti, extra
+
+
 def infonce_distill(score_s: torch.Tensor, score_t: torch.Tensor, temperature: float,
                     want_grad: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """A5 (criterion.py:56-68) + its closed-form gradient in one pass."""
@@ -224,9 +264,11 @@ def l2norm_forward(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float)
     return y, norm
 
 
-def l2norm_split(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+def l2norm_split(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float,
+                 pageflags: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """y = m*x / (||m*x|| + eps) emitted directly as the scorer's fp16 hi/lo planes (see `split_f32`): ((2, ..., 128) fp16,
-    absmax word).  One kernel instead of normalise -> absmax -> split, and no fp32 copy of y in HBM."""
+    absmax word).  One kernel instead of normalise -> absmax -> split, and no fp32 copy of y in HBM.  With `pageflags`
+    (x is (np, lp, 128)) non-finite unmasked rows are reported in their page's flag word on the way (`flag_nonfinite`)."""
     dev = _require_cuda(x)
     if x.shape[-1] != D or x.dtype != torch.float32:
         raise RuntimeError("l2norm kernel needs fp32 rows of width 128")
@@ -238,6 +280,7 @@ def l2norm_split(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float) -
     m = _mask_u8(rowmask, xc.shape[:-1], dev)
     with torch.cuda.device(dev):
         L.check(lib.evdr_l2norm_fwd_split(L.ptr(xc), L.ptr(m), rows, D, float(eps), None, None, L.ptr(planes), L.ptr(amax),
+                                          L.ptr(pageflags), int(xc.shape[-2]) if pageflags is not None else 1,
                                           L.current_stream_handle(dev)))
     return planes, amax
 
@@ -297,7 +340,8 @@ def adamw_advance(state: torch.Tensor, betas: Tuple[float, float]) -> None:
 
 def maxsim_backward_q(g: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],
                       argmax: torch.Tensor, nq: int, lq: int) -> torch.Tensor:
-    """A6, query side: dQ (nq, lq, 128) fp32 from upstream g (nq, np), the fp32 pages and the forward's argmax."""
+    """A6, query side: dQ (nq, lq, 128) fp32 from upstream g (nq, np), the fp32 pages and the forward's argmax.
+    Deterministic (per-segment partial sums added in a fixed order, no float atomics)."""
     dev = _require_cuda(g, P, argmax)
     npg, lp, d = P.shape
     lib = L.load()
@@ -305,7 +349,7 @@ def maxsim_backward_q(g: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Te
     qm = _mask_u8(qmask, (nq, lq), dev)
     pm = _mask_u8(pmask, (npg, lp), dev)
     dQ = torch.empty((nq, lq, d), dtype=torch.float32, device=dev)
-    ws = workspace(lib.evdr_maxsim_bwd_q_workspace(npg, lp), dev)
+    ws = workspace(lib.evdr_maxsim_bwd_q_workspace(nq, lq, npg, lp), dev)
     with torch.cuda.device(dev):
         L.check(lib.evdr_maxsim_bwd_q(L.ptr(gc), L.ptr(Pc), L.ptr(qm), L.ptr(pm), L.ptr(argmax), L.ptr(dQ), nq, lq, npg, lp, d,
                                       L.ptr(ws), ws.numel(), L.current_stream_handle(dev)))

@@ -19,6 +19,21 @@
  *   - dtype: EVDR_F32 inputs are scored to fp32 accuracy (fp16 hi/lo planes of the power-of-two-scaled
  *     tensors, 3 MFMA products, error below the rounding noise of an fp32 accumulation); EVDR_BF16
  *     inputs are used as they are (products exact in fp32).
+ *
+ * Non-finite inputs.  For finite inputs every result below is the reference's to the stated tolerance.  A NaN is handled
+ * where the reference's NaN lands (torch.max propagates it, evaluator/retrieval.py:201; the hardware max does not, so the
+ * inputs are inspected instead):
+ *   - a NaN in a VALID patch of page p (masked patches are replaced by -1e4 before the max and do not count)
+ *     -> out[q][p] = NaN for every q;
+ *   - a NaN in any token of query q, masked tokens included (NaN * 0 = NaN, :207) -> out[q][p] = NaN for every page p
+ *     that has a valid patch (an all-masked page keeps its exact 0);
+ *   - +-Inf elements are treated like NaN (torch yields +-Inf or NaN there depending on signs: the one divergence).
+ * Pages are inspected when they are prepared: evdr_maxsim_fwd does it per call; for a resident corpus call
+ * evdr_flag_nonfinite once after evdr_pack_pmask (evdr_l2norm_fwd_split can report its rows on the way).  Queries are
+ * inspected inside the kernel.  argmax entries of NaN pairs are unspecified; evdr_topk ranks NaN first (like torch.topk);
+ * the gradient kernels propagate whatever non-finite upstream gradient they are given, positions unspecified.
+ * Limitation: for queries longer than 32 tokens, a non-finite element in a MASKED token beyond the first 32 goes unseen
+ * if the query has no valid token in that 32-token slice.
  */
 #ifndef EVDR_H
 #define EVDR_H
@@ -38,6 +53,7 @@ extern "C" {
 
 #define EVDR_F32  0
 #define EVDR_BF16 1
+#define EVDR_F16  2            /* only evdr_flag_nonfinite: the hi plane of fp16 hi/lo planes */
 
 #define EVDR_TOPK_MAX 128      /* k_values max is 100 (evaluator/retrieval.py:223)   */
 
@@ -51,6 +67,7 @@ const char* evdr_last_error(void);       /* host string, thread-local, valid unt
  * pageflags: np uint32 (bit0 = page has a valid patch  [doc_has_token, evaluator/retrieval.py:192],
  *                       bit1 = page has a masked patch [-1e4 fill takes part in the max, :198],
  *                       bit2 = the valid patches form a prefix [0, first masked) or the whole page,
+ *                       bit3 = a valid patch holds a NaN / Inf element (set by evdr_flag_nonfinite, never here),
  *                       bits 16..31 = index of the first masked patch). */
 int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp,
                     uint32_t* tilemask, uint32_t* pageflags, void* hip_stream);
@@ -61,6 +78,13 @@ int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp,
  * plane-major.  amax_bits: 1 uint32 on the device = bits of max|x| (the kernels derive k from it; keep it with the
  * planes).  Three fp16 MFMA products lo*hi + hi*lo + hi*hi then give the fp32 dot product to below fp32 rounding noise. */
 int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, void* hip_stream);
+
+/* Report non-finite page content: sets bit 3 of pageflags[p] (made by evdr_pack_pmask) when a valid patch of page p holds a
+ * NaN or +-Inf element; the forward kernels then return NaN for that page ("Non-finite inputs" above).  P: (np, lp, 128)
+ * of dtype EVDR_F32, EVDR_BF16 or EVDR_F16 (the hi plane of fp16 hi/lo planes), `p_stride` elements between pages.  One
+ * read of P; flags are only ever set, re-run evdr_pack_pmask to clear them. */
+int evdr_flag_nonfinite(const void* P, int dtype, const uint8_t* pmask, int64_t np, int64_t lp, int64_t p_stride,
+                        uint32_t* pageflags, void* hip_stream);
 
 /* ---- A1: score_multi_vector_masked (evaluator/retrieval.py:166-213) ---------------------------------
  * out[q,p] = sum_n qmask[q,n] * has(p) * max_m( Q[q,n,:]·P[p,m,:] if pmask[p,m] else -1e4 )
@@ -105,8 +129,10 @@ int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const 
 
 /* ---- A6, query side: autograd of A1 w.r.t. Q (the reference's function is differentiable in both arguments) ---------
  * dQ[q,n,:] = qmask[q,n] * sum_p g[q,p] * has(p) * P[p, argmax[q,p,n], :]
- * g (nq,np) fp32; P (np,lp,128) fp32 dense; argmax from evdr_maxsim_fwd; dQ (nq,lq,128) fp32 is OVERWRITTEN. */
-size_t evdr_maxsim_bwd_q_workspace(int64_t np, int64_t lp);
+ * g (nq,np) fp32; P (np,lp,128) fp32 dense; argmax from evdr_maxsim_fwd; dQ (nq,lq,128) fp32 is OVERWRITTEN.
+ * Deterministic: with few (query, token) pairs the page range is split over workgroups, whose partial sums go to the
+ * workspace and are added in a fixed order (no float atomics) -- the same bits run after run. */
+size_t evdr_maxsim_bwd_q_workspace(int64_t nq, int64_t lq, int64_t np, int64_t lp);
 int evdr_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint8_t* pmask,
                       const uint16_t* argmax, float* dQ,
                       int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d,
@@ -142,10 +168,11 @@ int evdr_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask_or_n
 /* evdr_l2norm_fwd that also (or only: y_or_null = NULL) emits y in evdr_split_f32's format -- fp16 hi/lo planes
  * (2 * rows * 128 uint16) + the absmax word, here the constant bits of 1.0f since |y| <= 1 -- ready for
  * evdr_maxsim_fwd_prepared(nplanes = 2): the normalised student pages of a training step go to the scorer without an
- * fp32 round trip through HBM (mainv2_iter_distill_infonce.py:279-283). */
+ * fp32 round trip through HBM (mainv2_iter_distill_infonce.py:279-283).  pageflags_or_null (with rows_per_page = lp): a
+ * non-finite unmasked row sets bit 3 of its page's flag word on the way (see evdr_flag_nonfinite). */
 int evdr_l2norm_fwd_split(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps,
                           float* y_or_null, float* norm_or_null, uint16_t* planes, uint32_t* amax_bits,
-                          void* hip_stream);
+                          uint32_t* pageflags_or_null, int64_t rows_per_page, void* hip_stream);
 
 /* ---- A8: top-k per query row, replaces the Nq*N .item() loop (mainv2_iter_distill_infonce.py:311-317)
  * scores (nq, n) fp32 with row stride `row_stride`; idx_map_or_null (nq, n) int32 maps a column to

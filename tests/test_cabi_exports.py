@@ -103,3 +103,10 @@ def test_debug_hooks_round_trip(lib):
     assert lib.evdr_debug_set_fwd_variant(2) == 0 and lib.evdr_debug_set_fwd_variant(0) == 2
     assert lib.evdr_debug_set_pages_per_block(7) == 0 and lib.evdr_debug_set_pages_per_block(0) == 7
     assert lib.evdr_last_fwd_kernel() == b""            # nothing dispatched on this thread yet
+
+
+def test_pair_count_overflow_is_rejected(lib):
+    """(query, token) pairs are indexed in 32 bits inside the kernels: nq * lq >= 2^31 must come back as a status."""
+    from evdr_amd import _lib as L
+    rc = lib.evdr_maxsim_bwd(None, None, None, None, None, None, 70_000_000, 32, 4, 8, 128, None)
+    assert rc == L.EVDR_ERR_SHAPE and b"2^31" in lib.evdr_last_error()

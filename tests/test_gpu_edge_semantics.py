@@ -1,0 +1,246 @@
+"""Edge semantics the reference defines and the kernels must reproduce (or deviate from in a stated, tested way):
+non-finite embeddings (torch.max propagates NaN, evaluator/retrieval.py:198-207), equal scores straddling the top-k cut
+(the reference ranks ALL pairs, mainv2_iter_distill_infonce.py:311-317), degenerate teacher rows in the distillation loss
+(criterion.py:61 torch.argmax), and run-to-run determinism of dQ."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import maxsim_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _inputs(seed, nq=12, lq=32, npg=40, lp=77, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    Q = torch.nn.functional.normalize(torch.randn(nq, lq, 128, generator=g), dim=-1)
+    P = torch.nn.functional.normalize(torch.randn(npg, lp, 128, generator=g), dim=-1)
+    if dtype == torch.bfloat16:
+        Q, P = Q.bfloat16(), P.bfloat16()
+    qm = torch.ones(nq, lq, dtype=torch.bool)
+    qm[:, lq - 5:] = False
+    pm = torch.ones(npg, lp, dtype=torch.bool)
+    pm[3] = False                          # all-masked page
+    pm[7, lp // 2:] = False
+    return Q, P, qm, pm
+
+
+def _paths(Q, P, qm, pm):
+    """Every way the forward is reached: drop-in function (unprepared C entry), resident corpus (prepared entry)."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd.corpus import PageCorpus
+    from evdr_amd.evaluator.retrieval import score_multi_vector_masked
+    Qd, Pd, qd, pd = Q.to(DEV), P.to(DEV), qm.to(DEV), pm.to(DEV)
+    yield "drop-in", score_multi_vector_masked(Qd, Pd, qd, pd).cpu()
+    yield "corpus", PageCorpus.from_tensor(Pd, pd).score(Qd, qd).cpu()
+
+
+def _check_nan_positions(got, want, tag):
+    assert torch.equal(torch.isnan(got), torch.isnan(want)), f"{tag}: NaN positions differ"
+    ok = ~torch.isnan(want)
+    np.testing.assert_allclose(got[ok].numpy(), want[ok].numpy(), atol=1e-4, rtol=0, err_msg=tag)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_nan_lands_where_torch_max_puts_it(dtype):
+    """NaN in a valid patch -> that page's column; NaN in a MASKED patch -> nothing; NaN in a query token (valid or masked)
+    -> the query's row on every page with a valid patch, the all-masked page keeps its exact 0."""
+    Q, P, qm, pm = _inputs(1, dtype=dtype)
+    P[5, 10, 3] = float("nan")             # valid patch of page 5
+    P[7, 70, 0] = float("nan")             # masked patch of page 7: replaced by -1e4 before the max
+    P[3, 1, 1] = float("nan")              # all-masked page
+    Q[2, 4, 9] = float("nan")              # valid token of query 2
+    Q[6, 30, 0] = float("nan")             # MASKED token of query 6: NaN * 0 is still NaN in the reference
+    want = O.maxsim_masked(Q.float(), P.float(), qm, pm)
+    assert torch.isnan(want[:, 5]).all() and torch.isnan(want[:, 7]).sum() == 2          # column 7: only the two NaN queries
+    assert torch.isnan(want[2]).sum() == P.shape[0] - 1 and want[2, 3] == 0 and want[6, 3] == 0
+    for tag, got in _paths(Q, P, qm, pm):
+        _check_nan_positions(got, want, f"{tag}/{dtype}")
+        assert got[2, 3] == 0 and got[6, 3] == 0
+
+
+def test_nan_single_token_queries_and_long_queries():
+    """Lq = 1 (packed 32 to an MFMA tile inside the kernel): a NaN query poisons ITS row only.  Lq = 50 (two 32-token slices):
+    a NaN in a valid token of the second slice poisons the row."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd.evaluator.retrieval import score_multi_vector_masked
+    Q, P, _, pm = _inputs(2, nq=70, lq=1)
+    qm = torch.ones(70, 1, dtype=torch.bool)
+    Q[33, 0, 5] = float("nan")
+    P[9, 2, 2] = float("nan")
+    want = O.maxsim_masked(Q, P, qm, pm)
+    got = score_multi_vector_masked(Q.to(DEV), P.to(DEV), qm.to(DEV), pm.to(DEV)).cpu()
+    _check_nan_positions(got, want, "lq=1")
+    assert torch.isnan(got[33]).sum() == P.shape[0] - 1 and torch.isnan(got[:, 9]).all() and torch.isnan(got).sum() == 70 + 39 - 1
+    Q, P, _, pm = _inputs(3, nq=9, lq=50)
+    qm = torch.ones(9, 50, dtype=torch.bool)
+    qm[:, 45:] = False
+    Q[4, 40, 0] = float("nan")
+    want = O.maxsim_masked(Q, P, qm, pm)
+    got = score_multi_vector_masked(Q.to(DEV), P.to(DEV), qm.to(DEV), pm.to(DEV)).cpu()
+    _check_nan_positions(got, want, "lq=50")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_inf_is_reported_as_nan(dtype):
+    """The stated divergence (include/evdr.h): +-Inf elements are treated like NaN.  torch yields +-Inf or NaN at exactly
+    those (query, page) pairs with 32-token random queries; the kernels return NaN there and are exact everywhere else."""
+    Q, P, qm, pm = _inputs(4, dtype=dtype)
+    P[11, 5, 7] = float("inf")
+    Q[8, 2, 1] = float("-inf")
+    want = O.maxsim_masked(Q.float(), P.float(), qm, pm)
+    bad = ~torch.isfinite(want)
+    assert bad[:, 11].all() and bad[8, [0, 1, 2]].all() and not bad[8, 3]
+    for tag, got in _paths(Q, P, qm, pm):
+        assert torch.equal(torch.isnan(got), bad), tag
+        np.testing.assert_allclose(got[~bad].numpy(), want[~bad].numpy(), atol=1e-4, rtol=0)
+
+
+def test_one_diverged_page_does_not_change_the_scale_of_the_others():
+    """fp32 inputs are scored as fp16 hi/lo planes of x * 2^k with ONE k per tensor from its absmax: the absmax must skip
+    non-finite elements, or a single NaN page would leave every other page unscaled (lo plane denormal: ~1e-4 errors)."""
+    Q, P, qm, pm = _inputs(5)
+    P = P * 3e-4                            # small magnitudes: without the power-of-two scale the lo plane underflows
+    P[0, 0, 0] = float("nan")
+    want = O.maxsim_masked(Q.double(), P.double(), qm, pm).float()
+    for tag, got in _paths(Q, P, qm, pm):
+        ok = ~torch.isnan(want)
+        assert torch.isnan(got[:, 0]).all()
+        np.testing.assert_allclose(got[ok].numpy(), want[ok].numpy(), atol=2e-9, rtol=2e-6, err_msg=tag)
+
+
+def test_fused_student_reports_a_diverged_page():
+    """The training path: l2norm_split reports non-finite rows of the raw parameter on the way, the student scores of that
+    page are NaN (as l2_normalize + score_multi_vector_masked give in the reference), the others are untouched."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import driver
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(20, 41, 128, generator=g)
+    pm = torch.ones(20, 41, dtype=torch.bool)
+    pm[:, 38:] = False
+    Qb = torch.nn.functional.normalize(torch.randn(8, 32, 128, generator=g), dim=-1)
+    qm = torch.ones(8, 32, dtype=torch.bool)
+    x[4, 7, 100] = float("nan")
+    x[5, 39, 0] = float("nan")              # masked row: multiplied away by the mask?  No: NaN * 0 = NaN in Pbar * pmask ...
+    want = O.maxsim_masked(Qb, O.l2_normalize(x * pm.unsqueeze(-1)), qm, pm)
+    student = driver.FusedStudent(x.to(DEV), pm.to(DEV), lr=1e-3, weight_decay=1e-2)
+    got, _ = student.scores(Qb.to(DEV), qm.to(DEV))
+    # ... but that row is masked in the scorer too (pmask), so only page 4 is NaN in both
+    assert torch.isnan(want[:, 4]).all() and torch.isnan(want).sum() == 8
+    _check_nan_positions(got.cpu(), want, "fused student")
+
+
+def test_topk_ranks_nan_first_like_torch():
+    import evdr_amd  # noqa: F401
+    from evdr_amd import ops
+    g = torch.Generator().manual_seed(7)
+    s = torch.randn(5, 300, generator=g)
+    s[1, 17] = float("nan")
+    s[1, 250] = -float("nan")               # sign bit set: still "greatest"
+    s[3, 0] = float("inf")
+    s[3, 1] = float("-inf")
+    ts, ti = ops.topk(s.to(DEV), 10)
+    wt, wi = torch.topk(s, 10, dim=1)
+    assert torch.equal(torch.isnan(ts.cpu()), torch.isnan(wt))
+    assert sorted(ti[1, :2].tolist()) == [17, 250] and ti[3, 0].item() == 0
+    ok = ~torch.isnan(wt)
+    assert torch.equal(ts.cpu()[ok], wt[ok]) and torch.equal(ti.cpu()[ok].long(), wi[ok])
+
+
+def test_infonce_degenerate_teacher_rows():
+    """criterion.py:61 `score_t.argmax(dim=1)`: an all -inf row gives index 0, a row with NaNs the first NaN; the loss then
+    depends on the student row alone.  (The first version kept a sentinel index and read out of bounds.)"""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import ops
+    g = torch.Generator().manual_seed(8)
+    ss = torch.randn(6, 300, generator=g)
+    st = torch.randn(6, 300, generator=g)
+    st[1] = float("-inf")
+    st[2, 77] = float("nan")
+    st[2, 200] = float("nan")
+    st[3] = float("nan")
+    st[4, 5] = st[4].max() + 0.0            # exact tie with the maximum further right? make one: first index wins
+    j = int(st[4].argmax())
+    st[4, min(j + 1, 299)] = st[4, j]
+    tgt = st.argmax(dim=1)
+    assert tgt[1] == 0 and tgt[2] == 77 and tgt[3] == 0
+    want = torch.nn.functional.cross_entropy(ss / 0.1, tgt)
+    wgrad = torch.autograd.functional.jacobian(lambda z: torch.nn.functional.cross_entropy(z / 0.1, tgt), ss)
+    loss, grad = ops.infonce_distill(ss.to(DEV), st.to(DEV), 0.1, want_grad=True)
+    np.testing.assert_allclose(loss.item(), want.item(), rtol=1e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), wgrad.numpy(), atol=1e-6)
+
+
+def test_ties_straddling_the_topk_cut_rank_like_the_all_pairs_dict():
+    """Equal scores across rank k: the device cut keeps the lowest page indices, trec_eval (fed ALL pairs by the reference)
+    breaks ties by docid descending.  topk_with_ties hands the metric every tied candidate: identical metrics for every k."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import ops
+    from evdr_amd.evaluator.metrics import evaluate, results_from_topk
+    g = torch.Generator().manual_seed(9)
+    nq, n, k = 12, 400, 100
+    scores = (torch.randn(nq, n, generator=g) * 1.5).round() / 2          # heavily quantised: long tie runs everywhere
+    scores[0] = torch.randn(n, generator=g)                               # one row without ties
+    docids = [f"d{(i * 7919) % n:04d}" for i in range(n)]                 # docid order unrelated to the page index order
+    qkeys = [f"q{i}" for i in range(nq)]
+    rel = {}
+    for qi in range(nq):                                                   # relevant pages INSIDE the tie run at the cut
+        kth = torch.topk(scores[qi], k).values[-1]
+        tied = (scores[qi] == kth).nonzero().flatten().tolist()
+        rel[qkeys[qi]] = {docids[t]: 1 for t in tied[-3:]} | {docids[int(scores[qi].argmax())]: 2}
+    allpairs = {qkeys[qi]: {docids[j]: float(scores[qi, j]) for j in range(n)} for qi in range(nq)}     # the reference's dict
+    ks = [1, 3, 5, 10, 50, 70, 100]
+    want = evaluate(rel, allpairs, ks)
+    ts, ti, extra = ops.topk_with_ties(scores.to(DEV), k)
+    assert 0 not in extra and len(extra) >= nq - 2
+    got = evaluate(rel, results_from_topk(ts.cpu().numpy(), ti.cpu().numpy(), qkeys, docids, extra=extra), ks)
+    assert got == want
+    plain = evaluate(rel, results_from_topk(ts.cpu().numpy(), ti.cpu().numpy(), qkeys, docids), ks)
+    assert plain != want          # the bare device cut DOES rank differently here: that is what the extra candidates repair
+
+
+def test_eval_retrieval_with_duplicate_pages_matches_all_pairs():
+    """Through driver.eval_retrieval: duplicated pages give exactly equal MaxSim scores; 130 pages, 60 of them copies."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import driver
+    from evdr_amd.evaluator.metrics import evaluate
+    from evdr_amd.evaluator.retrieval import CustomRetrievalEvaluator
+    g = torch.Generator().manual_seed(10)
+    base = torch.randn(70, 40, 128, generator=g)
+    P = torch.cat([base, base[:1].repeat(60, 1, 1)])                      # page 0 sixty-one times
+    pm = torch.ones(130, 40, dtype=torch.bool)
+    Q = torch.nn.functional.normalize(base[:6, :12] + 0.1 * torch.randn(6, 12, 128, generator=g), dim=-1)
+    qm = torch.ones(6, 12, dtype=torch.bool)
+    docmap = {str(i): f"doc{(i * 37) % 130:03d}" for i in range(130)}
+    rel = {str(i): {docmap[str(i)]: 1, docmap[str(129 - i)]: 1} for i in range(6)}
+    ev = CustomRetrievalEvaluator(k_values=[1, 5, 50])
+    got = driver.eval_retrieval(ev, Q.to(DEV), qm.to(DEV), P.to(DEV), pm.to(DEV), rel, docmap, None, k=50)
+    sc = O.maxsim_masked(Q, O.l2_normalize(P * pm.unsqueeze(-1)), qm, pm)
+    allpairs = {str(i): {docmap[str(j)]: float(sc[i, j]) for j in range(130)} for i in range(6)}
+    # scores of duplicate pages are bit-equal on both sides, so tie sets agree; the values themselves differ by fp32 noise,
+    # which cannot reorder the distinct pages here (gaps >> 1e-4)
+    want = evaluate(rel, allpairs, [1, 5, 50])
+    got.pop("latency")
+    assert got == want
+
+
+def test_dq_is_deterministic_and_matches_the_oracle():
+    """The page-segment split of the dQ kernel (training shape: 1024 pairs -> 16 segments) reduces its partial sums in a
+    fixed order: bit-identical run to run, and equal to autograd of the oracle."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(11)
+    nq, lq, npg, lp = 32, 32, 500, 60
+    Q = torch.nn.functional.normalize(torch.randn(nq, lq, 128, generator=g), dim=-1)
+    P = torch.nn.functional.normalize(torch.randn(npg, lp, 128, generator=g), dim=-1)
+    qm = torch.rand(nq, lq, generator=g) > 0.1
+    pm = torch.rand(npg, lp, generator=g) > 0.1
+    up = torch.randn(nq, npg, generator=g)
+    assert L.load().evdr_maxsim_bwd_q_workspace(nq, lq, npg, lp) > 2 * nq * lq * 128 * 4        # > 1 segment at this shape
+    Qo = Q.clone().requires_grad_(True)
+    O.maxsim_masked(Qo, P, qm, pm).backward(up)
+    s, arg = ops.maxsim_forward(Q.to(DEV), P.to(DEV), qm.to(DEV), pm.to(DEV), want_argmax=True)
+    runs = [ops.maxsim_backward_q(up.to(DEV), P.to(DEV), qm.to(DEV), pm.to(DEV), arg, nq, lq).cpu() for _ in range(3)]
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    np.testing.assert_allclose(runs[0].numpy(), Qo.grad.numpy(), atol=2e-5, rtol=1e-5)
