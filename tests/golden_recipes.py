@@ -160,3 +160,28 @@ def npz_payload_case():
     qattn[1] = np.array([1, 1, 1, 0, 0, 1, 1])
     docid = obj([f"doc_{i}" for i in range(len(dlens))])
     return docs, attn, img, queries, qattn, docid
+
+
+def v3_case():
+    """Inputs of the secondary-loss / v3-augmentation step fixtures (tests/golden/make_golden_v3.py): a small
+    distillation problem -- (Qb, qmb, teacher raw, pmask_t, student init raw, pmask_s, hyper-parameters)."""
+    B, N, Ls, Lt, seed = 6, 16, 24, 300, 2026
+    gen = torch.Generator().manual_seed(seed)
+    Qb = _unit(gen, B, 32, 128)
+    qmb = torch.ones(B, 32, dtype=torch.bool)
+    qmb[:, 27:] = False
+    qmb[2, 9:] = False
+    Pt = torch.randn(N, Lt, 128, generator=gen)
+    pmt = torch.ones(N, Lt, dtype=torch.bool)
+    pmt[:, :3] = False
+    pmt[5, 200:] = False
+    blk = Lt // Ls
+    Pbar0 = Pt[:, : blk * Ls].reshape(N, Ls, blk, 128).mean(2) + 0.05 * torch.randn(N, Ls, 128, generator=gen)
+    pms = torch.ones(N, Ls, dtype=torch.bool)
+    pms[3, Ls - 5:] = False
+    pms[N - 2, Ls // 2:] = False
+    hp = {"k": 8, "temp": 2.0, "lr": 1e-3, "wd": 1e-2, "lambda_list": 1.0, "lambda_score": 0.5,
+          "q_noise_std": 0.05, "noise_seed": 77,
+          "lambda_mixed": 0.5, "mixup_alpha": 0.4, "mixup_seed": 78,
+          "lambda_aux": 0.3, "aux_docs": 3}
+    return Qb, qmb, Pt, pmt, Pbar0, pms, hp
