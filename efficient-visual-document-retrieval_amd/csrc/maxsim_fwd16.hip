@@ -350,7 +350,7 @@ __device__ __forceinline__ void xgroup_argmax(float& v, int& idx) {
     }
 }
 
-template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, bool SPQ2 = false>
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
 __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
     using frag = typename FragOf<NPL>::type;
     constexpr int WAVES = 8;
@@ -445,48 +445,41 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
     const uint32_t smem_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     // stage S = page (S / spp), tiles ST (S % spp) .. of that page (rows beyond the page are clamped: masked anyway)
     // Per-lane byte offset of this lane's 16 B inside a 1-KiB piece: LDS row (4 piece + lane/16) of the tile receives source
-    // chunk (lane%16) ^ (row & 15) of patch row (row0 + lane/16).  swz[q] = the swizzled chunk offset for piece & 3 == q.
+    // chunk (lane%16) ^ (row & 15) of patch row (row0 + lane/16):
     // The DMA's lane offset is zero-extended, so rows past the page end (masked anyway) are clamped by clamping the
     // scalar base row and giving each lane a non-negative row delta.
-    uint32_t swz[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) swz[q] = (uint32_t)(((lane & 15) ^ ((4 * q + (lane >> 4)) & 15)) << 4);
-    const uint32_t lgoff = (uint32_t)(lane >> 4) * 256u;
-    // piece i (of G) of this wave for stage S
-    auto issue_piece = [&](int S, int slot, int i, auto full_tag) {
+    // = ((c ^ g) << 4 | g << 8) ^ ((piece & 3) << 6) with c = lane % 16, g = lane / 16: ONE live VGPR and one v_xor per piece
+    const uint32_t voff0 = (uint32_t)((((lane & 15) ^ (lane >> 4)) << 4) | ((lane >> 4) << 8));
+    // piece i (of G) of this wave for stage k of page pgi.  [tlo, thi]: the tiles of the page that hold a valid patch
+    // (pages whose valid patches form one range, page flag bit 2): with a 2-slot ring every wait is vmcnt(0), so tiles
+    // outside it -- and tiles beyond the page -- are not fetched at all
+    auto stage_base = [&](int pgi, int k) -> const uint16_t* {          // first row of stage k of page pgi, plane 0
+        return p.P + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)(k * ST * EVDR_TILE_PATCHES) * EVDR_D;
+    };
+    auto issue_piece = [&](const uint16_t* sbp, int t0, int tlo, int thi, int slot, int i, auto full_tag) {
         constexpr bool KNOWN_FULL = decltype(full_tag)::value;       // caller guarantees the stage has all ST tiles
-        const int pgi = S / spp;
-        const int t0 = (S - pgi * spp) * ST;
         const int pc = wave * G + i;
         const int tis = pc / (8 * NPL);
         const int rem = pc - tis * (8 * NPL);
         const int pl = rem >> 3, piece = rem & 7;
-        // with a 2-slot ring every wait is vmcnt(0), so tiles beyond the page need not be fetched at all
-        if (!KNOWN_FULL && NSTAGE == 2 && t0 + tis >= p.ntiles) return;
-        const int row0 = (t0 + tis) * EVDR_TILE_PATCHES + piece * 4;                 // first patch row of the piece (uniform)
-        const int rbase = min(row0, p.lp - 1);
-        const uint16_t* sb = p.P + (int64_t)pl * p.p_plane_stride + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
-        uint32_t sw = swz[piece & 3], lg = lgoff;
-        if constexpr (SPQ2) {                                                        // rebuilt per piece: nothing stays live
-            uint32_t l = (uint32_t)lane;
-            asm volatile("" : "+v"(l));
-            sw = ((l & 15u) ^ ((4u * (piece & 3) + (l >> 4)) & 15u)) << 4;
-            lg = (l >> 4) * 256u;
-        }
-        uint32_t voff = sw + lg;
+        if (!KNOWN_FULL && (t0 + tis >= p.ntiles || t0 + tis < tlo || t0 + tis > thi)) return;
+        const int rrel = tis * EVDR_TILE_PATCHES + piece * 4;                        // piece's first row inside the stage (uniform)
+        const int row0 = t0 * EVDR_TILE_PATCHES + rrel;
+        int rb = rrel;
+        if (!KNOWN_FULL) rb = min(row0, p.lp - 1) - t0 * EVDR_TILE_PATCHES;          // clamp rows beyond the page (masked anyway)
+        const uint16_t* sb = sbp + (int64_t)pl * p.p_plane_stride + (int64_t)rb * EVDR_D;
+        uint32_t voff = voff0 ^ ((uint32_t)(piece & 3) << 6);
         if (!KNOWN_FULL && row0 + 3 >= p.lp)                                         // uniform: only a page's tail tile
-            voff = sw + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
+            voff = (voff & 0xFFu) + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - min(row0, p.lp - 1)) * 256u;
         lds_dma_16B_sbase(sb, voff,
                           __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + tis * TILE_B + pl * TILE_BYTES + piece * 1024));
     };
     // the extra (ST-th) tile of an extended last stage: piece `wave` of each plane of that tile, always clamped
-    auto issue_extra = [&](int S, int slot) {
-        const int pgi = S / spp;
-        const int k = S - pgi * spp;
-        if (!(ext && k == spp - 1)) return;
+    auto issue_extra = [&](int pgi, int k, int thi, int slot) {
+        if (!(ext && k == spp - 1) || thi < k * ST + ST) return;
         const int row0 = (k * ST + ST) * EVDR_TILE_PATCHES + wave * 4;
         const int rbase = min(row0, p.lp - 1);
-        const uint32_t voff = swz[wave & 3] + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
+        const uint32_t voff = ((voff0 ^ ((uint32_t)(wave & 3) << 6)) & 0xFFu) + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
             const uint16_t* sb = p.P + (int64_t)pl * p.p_plane_stride + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
@@ -494,16 +487,16 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                               __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + ST * TILE_B + pl * TILE_BYTES + wave * 1024));
         }
     };
-    auto issue_stage = [&](int S, int slot) {
+    auto issue_stage = [&](int pgi, int k, int tlo, int thi, int slot) {
+        const uint16_t* sbp = stage_base(pgi, k);
 #pragma unroll
-        for (int i = 0; i < G; ++i) issue_piece(S, slot, i, std::false_type{});
-        issue_extra(S, slot);
+        for (int i = 0; i < G; ++i) issue_piece(sbp, k * ST, tlo, thi, slot, i, std::false_type{});
+        issue_extra(pgi, k, thi, slot);
     };
-    // in-block refill: NPL pieces per tile of the straight-line block.  QW = 2 on fp16 planes is at the limit of the register
-    // file: there the refill is in-block only in the SPQ2 instantiation, which rebuilds the per-lane offsets of a piece
-    // from the lane id (6 VALU per piece) instead of keeping five VGPRs live through the block (the bf16 QW = 4 instance
-    // measured 0.8 % slower that way and keeps them)
-    constexpr bool SPREAD = (NSTAGE == 2) && (SPQ2 || !(NPL == 2 && QW == 2));
+    // in-block refill: NPL pieces per tile of the straight-line block, one scalar base pointer per stage and one live VGPR.
+    // Not in the QW = 2 argmax instance on fp16 planes, which is over the register budget as it is (it lost 7 us of 77 with
+    // the refill in-block, rocprofv3 on the training step): that one refills at the top of the stage.
+    constexpr bool SPREAD = !(NPL == 2 && QW == 2 && ARGMAX);
 
     typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
     cptr_t tilemask_c = (cptr_t)(uintptr_t)p.tilemask;
@@ -585,49 +578,149 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
             }
     };
 
-#pragma unroll
-    for (int i = 0; i < NSTAGE - 1; ++i)
-        if (i < nstages) issue_stage(i, i);
+    static_assert(NSTAGE == 2, "the stage cursors below keep exactly one stage in flight");
+    // ---- stage sequence.  A page whose valid patches form ONE range [va, vb) (page flag bit 2: all valid, a ragged
+    // prefix, an image between masked text tokens -- what utils/preprocess_data.py:101 produces) is walked only over the
+    // stages that hold a valid patch, and only the tiles inside the range are fetched: a 700-patch page of a 1030-patch
+    // corpus costs 3 stages and 22 tiles, not 4 and 33.  Pages with holes walk all their stages and read mask words.
+    // Two cursors run over the same sequence one stage apart: `nx*` = the stage being fetched, `c*` = the one computed.
+    auto page_span = [&](uint32_t pf, int& klo, int& khi, int& tlo, int& thi) {
+        klo = 0; khi = spp; tlo = 0; thi = p.ntiles - 1;
+        if (pf & 4u) {
+            const int va = (int)((pf >> 4) & 0xFFFu), vb = (int)(pf >> 16);
+            if (vb > va) {
+                tlo = va >> 5;
+                thi = (vb - 1) >> 5;
+                klo = min(tlo / ST, spp - 1);
+                khi = min(thi / ST, spp - 1) + 1;
+            } else {                                    // no valid patch at all: one stage, nothing fetched
+                khi = 1; tlo = 1; thi = 0;
+            }
+        }
+    };
+    // cursor state is kept small (it lives in SGPRs across the MFMA block): page, stage and flag word; spans are re-derived
+    int npgi = 0, nk;                                   // fetch cursor: page, stage
+    uint32_t npf = pageflags_c[pg0];
+    // flag word of the page AFTER the fetch cursor's, loaded a whole page before it is needed: the first stage of the next
+    // page is chosen from it, and a scalar-load latency in front of every page's first refill would sit on the critical
+    // path of HBM-bound launches
+    uint32_t apf = npages > 1 ? pageflags_c[pg0 + 1] : 0u;
+    {
+        int khi0, tlo0, thi0;
+        page_span(npf, nk, khi0, tlo0, thi0);
+        issue_stage(0, nk, tlo0, thi0, 0);
+    }
     if constexpr (DIAG) d_pro = stamp() - d_t0;
     const bool spread_ok = p.inblock_refill != 0;
-    int slot = 0, S = 0;
-    for (int pgi = 0; pgi < npages; ++pgi) {
+    int slot = 0;
+    bool page_open = true;                              // the compute cursor is at the first stage of its page
+    uint32_t pflags = 0u;
+    while (npgi < npages) {
+        // the compute cursor takes over the stage that was fetched last; the fetch cursor moves on
+        const int pgi = npgi, k = nk;
         const int page = pg0 + pgi;
-        const uint32_t pflags = pageflags_c[page];
-        const int vlen = (pflags & 4u) ? ((pflags & 2u) ? (int)(pflags >> 16) : p.lp) : -1;    // -1: page with holes
+        if (page_open) pflags = npf;
+        // range pages: [va, vb); pages with holes: va = vb = -1 (mask words decide)
+        const int va = (pflags & 4u) ? (int)((pflags >> 4) & 0xFFFu) : -1;
+        const int vb = (pflags & 4u) ? (int)(pflags >> 16) : -1;
+        // index torch.max reports for an all-masked page / where the -1e4 fill first appears
+        const int first_masked = (pflags & 4u) ? (va > 0 ? 0 : vb) : (int)(pflags >> 16);
+        if (page_open) {
 #pragma unroll
-        for (int j = 0; j < QW; ++j) {
-            // NPL = 1: a masked patch inside [0, lp) puts -1e4 into the max right away; NPL = 2 works in scaled units and
-            // lets the -1e4 join at the page end
-            run[j][0] = run[j][1] = (NPL == 1 && (pflags & 2u)) ? -1e4f : neg_inf();
-            ridx[j][0] = ridx[j][1] = (NPL == 1) ? (int)(pflags >> 16) : 0;
+            for (int j = 0; j < QW; ++j) {
+                // NPL = 1: a masked patch inside [0, lp) puts -1e4 into the max right away; NPL = 2 works in scaled units and
+                // lets the -1e4 join at the page end
+                run[j][0] = run[j][1] = (NPL == 1 && (pflags & 2u)) ? -1e4f : neg_inf();
+                ridx[j][0] = ridx[j][1] = (NPL == 1) ? first_masked : 0;
+            }
         }
-
-        for (int k = 0; k < spp; ++k, ++S) {
-            if constexpr (DIAG) d_a = stamp();
-            if (NSTAGE >= 3 && S + 1 < nstages) wait_vmcnt<G>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if constexpr (DIAG) { const unsigned long long t = stamp(); d_bar += t - d_a; d_a = t; }
-            const int nslot = slot == 0 ? NSTAGE - 1 : slot - 1;
-            const bool refill = S + NSTAGE - 1 < nstages;
+        bool page_close;
+        {
+            int klo, khi, tlo, thi;
+            page_span(pflags, klo, khi, tlo, thi);
+            page_close = (k + 1 == khi);
+        }
+        if (!page_close) {
+            ++nk;
+        } else {
+            ++npgi;
+            if (npgi < npages) {
+                npf = apf;
+                if (npgi + 1 < npages) apf = pageflags_c[pg0 + npgi + 1];
+                int khi, tlo, thi;
+                page_span(npf, nk, khi, tlo, thi);
+            }
+        }
+        const bool refill = npgi < npages;
+        {
+            // ---- everything this stage's control flow and the refill need is worked out BEFORE the wait for the stage's
+            // data: flag / mask-word loads, spans and addresses overlap with the wait, and between the barrier and the first
+            // LDS-DMA instruction of the refill only the DMA issue itself is left (in HBM-bound launches that gap is dead time
+            // of the corpus stream: 511 instructions with seven scalar-load waits before, a few dozen now)
+            const int nslot = slot ^ 1;
             const int t0 = k * ST;
-            // a stage runs as the straight-line block when all its ST tiles are fully valid: from the valid length for
-            // prefix-style pages, from the mask words (one scalar load each, before the block) for pages with holes -- e.g.
-            // a few masked text tokens in front of the image patches leave all but the first stage of a page fast
-            bool fast = active && (vlen - t0 * EVDR_TILE_PATCHES >= ST * EVDR_TILE_PATCHES);
-            if (vlen < 0 && active && t0 + ST <= p.ntiles) {
-                uint32_t all = 0xFFFFFFFFu;
+            // a stage runs as the straight-line block when all its ST tiles are fully valid: from the valid range for
+            // range pages, from the mask words (one scalar load each) for pages with holes.
+            // bf16 kernels: the FIRST tile of the stage may be partial (the masked text tokens in front of the image patches
+            // put the partial tile at the head of a page's first stage): its two half-tile steps then take the per-patch
+            // select inside the same straight-line block (`headmask` = that tile's mask word, all ones otherwise)
+            uint32_t headmask = 0xFFFFFFFFu;
+            bool fast;
+            if (va >= 0) {
+                const int h0 = va - t0 * EVDR_TILE_PATCHES;            // valid patches start here, relative to the stage
+                fast = active && vb >= (t0 + ST) * EVDR_TILE_PATCHES && h0 < (NPL == 1 ? EVDR_TILE_PATCHES : 1);
+                if (h0 > 0 && h0 < EVDR_TILE_PATCHES) headmask = ~((1u << h0) - 1u);
+            } else {
+                fast = false;
+                if (active && t0 + ST <= p.ntiles) {
+                    uint32_t all = 0xFFFFFFFFu;
 #pragma unroll
-                for (int i = 0; i < ST; ++i) all &= tilemask_c[(int64_t)page * p.ntiles + t0 + i];
-                fast = (all == 0xFFFFFFFFu);
+                    for (int i = 1; i < ST; ++i) all &= tilemask_c[(int64_t)page * p.ntiles + t0 + i];
+                    headmask = tilemask_c[(int64_t)page * p.ntiles + t0];
+                    fast = (all == 0xFFFFFFFFu) && (NPL == 1 || headmask == 0xFFFFFFFFu);
+                }
             }
             // In-block refill: when this stage runs the straight-line block AND the next stage is a full one (all ST tiles
             // exist and lie inside the page rows), its LDS-DMA pieces are issued NPL per tile INSIDE the block, where their
-            // scalar/address work hides under MFMAs; otherwise the refill is issued here, right after the barrier.
-            const bool next_full = refill && (k + 1 < spp ? (k + 2) * ST * EVDR_TILE_PATCHES <= p.lp
-                                                          : ST * EVDR_TILE_PATCHES <= p.lp);
+            // scalar/address work hides under MFMAs; otherwise the refill is issued right after the barrier.
+            // (In-block, the whole next stage is fetched, also tiles outside the page's valid range.)
+            const bool next_rows = (nk + 1) * ST * EVDR_TILE_PATCHES <= p.lp;     // every row of the next stage exists
+            const bool next_full = refill && next_rows;
             const bool spread = SPREAD && fast && next_full && spread_ok;
-            if (refill && !spread) issue_stage(S + NSTAGE - 1, nslot);
+            // one base pointer for the whole next stage (two SGPRs), the tile window of its page, and which of this wave's G
+            // pieces lie inside it
+            const uint16_t* nbase = stage_base(refill ? npgi : pgi, refill ? nk : k);
+            const int nt0 = nk * ST;
+            int ntlo = 0, nthi = -1;
+            uint32_t want = 0u;
+            if (refill && !spread) {
+                int klo, khi;
+                page_span(npf, klo, khi, ntlo, nthi);
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const int t = nt0 + (wave * G + i) / (8 * NPL);
+                    want |= (t >= ntlo && t <= nthi && t < p.ntiles) ? (1u << i) : 0u;
+                }
+            }
+            if constexpr (DIAG) d_a = stamp();
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if constexpr (DIAG) { const unsigned long long t = stamp(); d_bar += t - d_a; d_a = t; }
+            if (refill && !spread) {
+                if (next_rows) {                                        // no row of the stage needs clamping: constant offsets
+                    if (want == (1u << G) - 1u) {
+#pragma unroll
+                        for (int i = 0; i < G; ++i) issue_piece(nbase, nt0, 0, 0, nslot, i, std::true_type{});
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < G; ++i)
+                            if ((want >> i) & 1u) issue_piece(nbase, nt0, 0, 0, nslot, i, std::true_type{});
+                    }
+                    issue_extra(npgi, nk, nthi, nslot);
+                } else {
+                    issue_stage(npgi, nk, ntlo, nthi, nslot);
+                }
+            }
             if constexpr (DIAG) { const unsigned long long t = stamp(); d_ref += t - d_a; d_a = t; }
             const char* sbase = a_lane + slot * STAGE_BYTES;
             const int nt = (k == spp - 1) ? p.ntiles - t0 : ST;          // tiles in this stage (ST + 1 in an extended last stage)
@@ -635,9 +728,9 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
             auto generic_tile = [&](int tis) {
                 const int tip = t0 + tis;
                 uint32_t tm;
-                if (vlen >= 0) {
-                    const int rem = vlen - tip * EVDR_TILE_PATCHES;
-                    tm = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+                if (va >= 0) {
+                    const int lo = max(va - tip * EVDR_TILE_PATCHES, 0), hi = min(vb - tip * EVDR_TILE_PATCHES, 32);
+                    tm = hi > lo ? ((hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
                 } else {
                     tm = tilemask_c[(int64_t)page * p.ntiles + tip];
                 }
@@ -654,9 +747,10 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
             if (active) {
                 if (fast) {
                     // ---- fast stage: ST all-valid tiles of one page, one basic block (two instances: with / without refill)
-                    auto fast_block = [&](auto spread_tag, auto young_tag) {
+                    auto fast_block = [&](auto spread_tag, auto young_tag, auto head_tag) {
                         constexpr bool SP = decltype(spread_tag)::value;
                         constexpr bool YOUNG = decltype(young_tag)::value;   // second-dispatched half of the workgroup
+                        constexpr bool HEAD = decltype(head_tag)::value;     // the stage's first tile is partial (mask `headmask`)
                         // self-balancing priority: 3,2,1,0 over the quarters of the block.  The two waves of a SIMD run this
                         // same block; the one the arbiter favours reaches the lower-priority quarters first and yields, so
                         // both arrive at the stage barrier together instead of one idling while the other finishes alone.
@@ -687,11 +781,11 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                             for (int tis = 0; tis < ST; ++tis) {
                                 const int pbase = (t0 + tis) * EVDR_TILE_PATCHES;
                                 set_prio(2 * tis);
-                                chains_full(alo, pbase);
+                                if (HEAD && tis == 0) chains_masked(alo, headmask & 0xFFFFu, pbase); else chains_full(alo, pbase);
                                 if (tis + 1 < ST) load_half(alo, sbase, tis + 1, 0);
-                                if constexpr (SP) issue_piece(S + 1, nslot, tis, std::true_type{});
+                                if constexpr (SP) issue_piece(nbase, nt0, 0, 0, nslot, tis, std::true_type{});
                                 set_prio(2 * tis + 1);
-                                chains_full(ahi, pbase + 16);
+                                if (HEAD && tis == 0) chains_masked(ahi, headmask >> 16, pbase + 16); else chains_full(ahi, pbase + 16);
                                 if (tis + 1 < ST) load_half(ahi, sbase, tis + 1, 1);
                             }
                         } else {
@@ -724,7 +818,7 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                                 if constexpr (SP) {
                                     if ((h & 1) == 0) {
 #pragma unroll
-                                        for (int pl = 0; pl < NPL; ++pl) issue_piece(S + 1, nslot, (h >> 1) * NPL + pl, std::true_type{});
+                                        for (int pl = 0; pl < NPL; ++pl) issue_piece(nbase, nt0, 0, 0, nslot, (h >> 1) * NPL + pl, std::true_type{});
                                     }
                                 }
 #pragma unroll
@@ -749,21 +843,118 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                         }
                     };
                     // one straight-line instance per (refill placement, workgroup half): no run-time branch inside the block
-                    if (BAL && wave >= WAVES / 2) {
-                        if (spread) fast_block(std::true_type{}, std::true_type{}); else fast_block(std::false_type{}, std::true_type{});
+                    auto by_half = [&](auto sp, auto hd) {
+                        if (BAL && wave >= WAVES / 2) fast_block(sp, std::true_type{}, hd); else fast_block(sp, std::false_type{}, hd);
+                    };
+                    if constexpr (NPL == 1) {
+                        if (headmask != 0xFFFFFFFFu) {
+                            if (spread) by_half(std::true_type{}, std::true_type{}); else by_half(std::false_type{}, std::true_type{});
+                        } else {
+                            if (spread) by_half(std::true_type{}, std::false_type{}); else by_half(std::false_type{}, std::false_type{});
+                        }
                     } else {
-                        if (spread) fast_block(std::true_type{}, std::false_type{}); else fast_block(std::false_type{}, std::false_type{});
+                        if (spread) by_half(std::true_type{}, std::false_type{}); else by_half(std::false_type{}, std::false_type{});
                     }
-                    if (spread) issue_extra(S + 1, nslot);               // the next stage's tail-tile pieces, after the block
+                    if (spread) issue_extra(npgi, nk, p.ntiles, nslot);      // the next stage's tail-tile pieces, after the block
                     if constexpr (DIAG) { const unsigned long long t = stamp(); d_fast += t - d_a; d_a = t; }
                     if (nt > ST) generic_tile(ST);                       // tail tile riding in this (last) stage
                 } else {
-                    for (int tis = 0; tis < nt; ++tis) generic_tile(tis);
+                    // ---- partially valid stage (the boundary stage of a ragged page, a stage with a few masked patches --
+                    // e.g. the text-prefix tokens in front of the image patches, utils/preprocess_data.py:101): runs of FULL
+                    // tiles go through a rolled per-tile loop with the fast block's fragment prefetch and no mask logic in
+                    // between (one tile = 32 x QW MFMAs per loop-back); only partial tiles take the per-half generic path, and
+                    // empty tiles cost nothing.  Which tiles are full: from the valid length, or from the mask words.
+                    uint32_t fullbits = 0u;
+                    if (va >= 0) {                                    // tiles [ceil(va/32), floor(vb/32)) of the page are full
+                        int f0 = ((va + 31) >> 5) - t0, f1 = (vb >> 5) - t0;
+                        f0 = f0 < 0 ? 0 : f0;
+                        f1 = f1 > nt ? nt : f1;
+                        if (f1 > f0) fullbits = ((1u << f1) - 1u) & ~((1u << f0) - 1u);
+                    } else {
+                        for (int tis = 0; tis < nt; ++tis)
+                            fullbits |= (tilemask_c[(int64_t)page * p.ntiles + t0 + tis] == 0xFFFFFFFFu ? 1u : 0u) << tis;
+                    }
+                    auto full_run = [&](int tis0, int len) {
+                        if constexpr (NPL == 1) {
+                            frag alo[NPL][4], ahi[NPL][4];
+                            load_half(alo, sbase, tis0, 0);
+                            load_half(ahi, sbase, tis0, 1);
+#pragma unroll 1
+                            for (int i = 0; i < len; ++i) {
+                                const int tis = tis0 + i;
+                                const int nx = (i + 1 < len) ? tis + 1 : tis;        // the last prefetch re-reads its own tile
+                                const int pbase = (t0 + tis) * EVDR_TILE_PATCHES;
+                                chains_full(alo, pbase);
+                                load_half(alo, sbase, nx, 0);
+                                chains_full(ahi, pbase + 16);
+                                load_half(ahi, sbase, nx, 1);
+                            }
+                        } else {
+                            auto load_plane = [&](frag (&a)[4], int h, int pl) {
+                                const char* tb = sbase + (h >> 1) * TILE_B + (h & 1) * (16 * EVDR_D * 2) + pl * TILE_BYTES;
+#pragma unroll
+                                for (int s4 = 0; s4 < 4; ++s4) a[s4] = *reinterpret_cast<const frag*>(tb + (((4 * s4) ^ gx) << 4));
+                            };
+                            frag al[4], ah[4];
+                            load_plane(al, 2 * tis0, 1);
+                            load_plane(ah, 2 * tis0, 0);
+#pragma unroll 1
+                            for (int i = 0; i < len; ++i) {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    const int h = 2 * (tis0 + i) + u;
+                                    const int hn = (u == 0 || i + 1 < len) ? h + 1 : h;
+                                    f32x4v acc[QW][2];
+#pragma unroll
+                                    for (int j = 0; j < QW; ++j) acc[j][0] = acc[j][1] = f32x4v{0, 0, 0, 0};
+#pragma unroll
+                                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                                        for (int j = 0; j < QW; ++j)
+#pragma unroll
+                                            for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(al[s4], bq[j][0][t][s4], acc[j][t]);
+                                    load_plane(al, hn, 1);
+#pragma unroll
+                                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                                        for (int j = 0; j < QW; ++j)
+#pragma unroll
+                                            for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][1][t][s4], acc[j][t]);
+#pragma unroll
+                                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                                        for (int j = 0; j < QW; ++j)
+#pragma unroll
+                                            for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][0][t][s4], acc[j][t]);
+                                    load_plane(ah, hn, 0);
+                                    const int pb = (t0 + (h >> 1)) * EVDR_TILE_PATCHES + 16 * (h & 1) + 4 * g;
+#pragma unroll
+                                    for (int j = 0; j < QW; ++j)
+#pragma unroll
+                                        for (int t = 0; t < 2; ++t) fold(acc[j][t], j, t, pb);
+                                }
+                            }
+                        }
+                    };
+                    for (int tis = 0; tis < nt;) {
+                        const uint32_t rest = fullbits >> tis;
+                        if (rest & 1u) {
+                            int len = __builtin_ctz(~rest);                           // length of the run of full tiles
+                            len = len > nt - tis ? nt - tis : len;
+                            full_run(tis, len);
+                            tis += len;
+                        } else {
+                            generic_tile(tis);
+                            ++tis;
+                        }
+                    }
                 }
             }
             if constexpr (DIAG) { if (!fast) { const unsigned long long t = stamp(); d_gen += t - d_a; d_a = t; } }
-            slot = (slot == NSTAGE - 1) ? 0 : slot + 1;
+            slot ^= 1;
         }
+        page_open = page_close;
+        if (!page_close) continue;
         if constexpr (DIAG) d_a = stamp();
         // ---- page finished: fold lane groups, weight, reduce over tokens, store
         if (active) {
@@ -779,13 +970,16 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                     if constexpr (NPL == 2) {
                         v *= inv;
                         if (pflags & 2u) {                                 // the masked patches' -1e4 joins the max here
-                            const int fm = (int)(pflags >> 16);
+                            const int fm = first_masked;
                             const bool take = (-1e4f > v) || (-1e4f == v && fm < bi);
                             v = take ? -1e4f : v;
                             bi = take ? fm : bi;
                         }
                     }
-                    const int tok = 16 * t + c;
+                    // (opaque per page: otherwise the 64-bit per-lane output offsets of all (query, token) slots are hoisted out of
+                    // the page loop -- 16 VGPRs that end up spilled, with their reloads landing inside the MFMA blocks)
+                    int tok = 16 * t + c;
+                    asm volatile("" : "+v"(tok));
                     if (p.per_token) {
                         // packed single-token queries: one score (and argmax) per token, no sum over the pack
                         const int64_t qrow = (int64_t)qreal[j] * 32 + tok;
@@ -824,18 +1018,18 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
     }
 }
 
-template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, bool SPQ2 = false>
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
 hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
     constexpr int LDS = NSTAGE * (ST + 1) * NPL * TILE_BYTES;
-    auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC, SPQ2>;
+    auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC>;
     static uint64_t attr_devs = 0;
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, 8 * QW);
     static const char* const name = [] {
         static char buf[96];
-        snprintf(buf, sizeof(buf), "maxsim_fwd16s_kernel<%d,%d,%s,%d,%d,%s,%s,%d,%s>", QW, NPL, ARGMAX ? "true" : "false", ST, NSTAGE,
-                 DIAG ? "true" : "false", BAL ? "true" : "false", OCC, SPQ2 ? "true" : "false");
+        snprintf(buf, sizeof(buf), "maxsim_fwd16s_kernel<%d,%d,%s,%d,%d,%s,%s,%d>", QW, NPL, ARGMAX ? "true" : "false", ST, NSTAGE,
+                 DIAG ? "true" : "false", BAL ? "true" : "false", OCC);
         return (const char*)buf;
     }();
     evdr_note_fwd_kernel(name);
@@ -889,16 +1083,12 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes,
             return partial ? r - 1 : r;
         };
         const bool st3 = geom == 10 || (geom != 11 && generic_full_tiles(3) < generic_full_tiles(4));   // 10 / 11: A/B force
-        // QW = 2 without argmax: in-block refill with the lane offsets rebuilt per piece (SPQ2): 283 -> 273 us on the 32 x 500
-        // teacher forward, +1..3 % on large problems; geom 9 = A/B without it.  The argmax instance is already 48 registers
-        // over budget and loses 7 us of 77 with it (rocprofv3 on the training step), so it refills at the top of the stage.
         if (st3) {
             if (want_argmax) return qw == 2 ? launch16s<2, 2, true, 3, 2, false, true>(p, stream) : launch16s<1, 2, true, 3, 2, false, true>(p, stream);
-            return qw == 2 ? launch16s<2, 2, false, 3, 2, false, true, 2, true>(p, stream) : launch16s<1, 2, false, 3, 2, false, true>(p, stream);
+            return qw == 2 ? launch16s<2, 2, false, 3, 2, false, true>(p, stream) : launch16s<1, 2, false, 3, 2, false, true>(p, stream);
         }
         if (want_argmax) return qw == 2 ? launch16s<2, 2, true, 4, 2, false, true>(p, stream) : launch16s<1, 2, true, 4, 2, false, true>(p, stream);
-        if (qw == 2) return geom == 9 ? launch16s<2, 2, false, 4, 2, false, true>(p, stream) : launch16s<2, 2, false, 4, 2, false, true, 2, true>(p, stream);
-        return launch16s<1, 2, false, 4, 2, false, true>(p, stream);
+        return qw == 2 ? launch16s<2, 2, false, 4, 2, false, true>(p, stream) : launch16s<1, 2, false, 4, 2, false, true>(p, stream);
     }
     if (want_argmax) return qw == 2 ? launch16s<2, 1, true, 8, 2, false, true>(p, stream) : launch16s<1, 1, true, 8, 2, false, true>(p, stream);
 #ifdef EVDR_EXPERIMENT

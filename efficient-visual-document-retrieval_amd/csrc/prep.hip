@@ -12,7 +12,7 @@ __global__ void __launch_bounds__(64) pack_pmask_kernel(const uint8_t* __restric
     const int page = blockIdx.x;
     const int lane = threadIdx.x;
     const uint8_t* row = pmask ? pmask + (int64_t)page * lp : nullptr;
-    uint32_t any_valid = 0, first_masked = 0xFFFFu, nvalid = 0;
+    uint32_t first_masked = 0xFFFFu, first_valid = 0xFFFFu, end_valid = 0u, nvalid = 0;
     for (int t = lane; t < ntiles; t += 64) {
         uint32_t w = 0, inrange = 0;
         const int base = t * 32;
@@ -25,23 +25,31 @@ __global__ void __launch_bounds__(64) pack_pmask_kernel(const uint8_t* __restric
             }
         }
         tilemask[(int64_t)page * ntiles + t] = w;
-        any_valid |= w;
         nvalid += (uint32_t)__builtin_popcount(w);
+        if (w) {
+            first_valid = min(first_valid, (uint32_t)(base + __builtin_ctz(w)));
+            end_valid = max(end_valid, (uint32_t)(base + 32 - __builtin_clz(w)));
+        }
         const uint32_t masked = inrange & ~w;
         if (masked) first_masked = min(first_masked, (uint32_t)(base + __builtin_ctz(masked)));
     }
     // wave reductions
     for (int off = 32; off > 0; off >>= 1) {
-        any_valid |= __shfl_xor(any_valid, off);
         first_masked = min(first_masked, (uint32_t)__shfl_xor((int)first_masked, off));
+        first_valid = min(first_valid, (uint32_t)__shfl_xor((int)first_valid, off));
+        end_valid = max(end_valid, (uint32_t)__shfl_xor((int)end_valid, off));
         nvalid += (uint32_t)__shfl_xor((int)nvalid, off);
     }
     if (lane == 0) {
-        uint32_t f = (any_valid ? 1u : 0u);
-        if (first_masked != 0xFFFFu) f |= 2u | (first_masked << 16);
-        // bit2: the valid patches are exactly the prefix [0, first_masked) (or the whole page): the tile masks are then a
-        // function of that length alone and the forward kernel derives them without loading the mask words
-        if (first_masked == 0xFFFFu || nvalid == first_masked) f |= 4u;
+        uint32_t f = (nvalid ? 1u : 0u);
+        if (first_masked != 0xFFFFu) f |= 2u;
+        // bit2: the valid patches are exactly ONE range [va, vb) (the whole page, a ragged prefix, an image between masked
+        // text tokens, or nothing at all): va in bits 4..15, vb in bits 16..31.  The forward kernel then derives every tile
+        // mask from the two numbers, walks only the stages inside the range and fetches only its tiles.  Otherwise (holes,
+        // or va >= 4096) bits 16..31 hold the index of the first masked patch and the mask words are read.
+        const uint32_t va = nvalid ? first_valid : 0u, vb = nvalid ? end_valid : 0u;
+        if (nvalid == vb - va && va < 4096u) f |= 4u | (va << 4) | (vb << 16);
+        else f |= (first_masked == 0xFFFFu ? 0u : first_masked) << 16;
         pageflags[page] = f;
     }
 }

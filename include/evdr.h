@@ -64,11 +64,14 @@ const char* evdr_last_error(void);       /* host string, thread-local, valid unt
 
 /* Pack a (np, lp) byte mask into per-32-patch tile words + per-page flags.
  * tilemask: np * ceil(lp/32) uint32 (bit m of word t = pmask[p][32 t + m]);
- * pageflags: np uint32 (bit0 = page has a valid patch  [doc_has_token, evaluator/retrieval.py:192],
- *                       bit1 = page has a masked patch [-1e4 fill takes part in the max, :198],
- *                       bit2 = the valid patches form a prefix [0, first masked) or the whole page,
- *                       bit3 = a valid patch holds a NaN / Inf element (set by evdr_flag_nonfinite, never here),
- *                       bits 16..31 = index of the first masked patch). */
+ * pageflags: np uint32:
+ *   bit0 = page has a valid patch  [doc_has_token, evaluator/retrieval.py:192]
+ *   bit1 = page has a masked patch [the -1e4 fill takes part in the max, :198]
+ *   bit2 = the valid patches are exactly ONE range [va, vb) -- the whole page, a ragged prefix, an image between masked
+ *          text tokens (what utils/preprocess_data.py:101 produces), or no patch at all: then va = bits 4..15 (< 4096),
+ *          vb = bits 16..31, and the kernels walk / fetch only that range; otherwise (holes) bits 16..31 = index of the
+ *          first masked patch and the tile words decide
+ *   bit3 = a valid patch holds a NaN / Inf element (set by evdr_flag_nonfinite, never here). */
 int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp,
                     uint32_t* tilemask, uint32_t* pageflags, void* hip_stream);
 
