@@ -56,23 +56,23 @@ struct EvdrFwdParams {
 // Pick the ppb in [lo, 64] that minimises rounds x (ppb + fixed): this avoids e.g. 1539 workgroups = 6 full rounds + a
 // seventh for 3 workgroups.  lo: a workgroup should stream >= ~64 tiles, otherwise the fixed cost dominates -- unless
 // that would leave CUs without any workgroup.  Many rounds (>= 64) need no tuning: take 64 pages.
-static inline int evdr_pages_per_block(int64_t np, int64_t n_qgroups, int64_t ntiles) {
+static inline int evdr_pages_per_block(int64_t np, int64_t n_qgroups, int64_t ntiles, int64_t slots = 256) {
     const int64_t total = np * n_qgroups;
     int64_t lo = (64 + ntiles - 1) / ntiles;
-    const int64_t fill = (total + 255) / 256;            // pages per workgroup that still gives every CU one workgroup
+    const int64_t fill = (total + slots - 1) / slots;    // pages per workgroup that still gives every workgroup slot one workgroup
     if (lo > fill) lo = fill;
     if (lo < 1) lo = 1;
-    int64_t hi = total / 1536;                           // ~6 rounds
+    int64_t hi = total / (6 * slots);                    // ~6 rounds
     if (hi > 64) hi = 64;
     if (hi < lo) hi = lo;
     if (hi > np) hi = np;
     if (lo > hi) lo = hi;
-    if (total / (256 * hi) >= 64) return (int)hi;        // tail round <= 1.5 % whatever the choice
+    if (total / (slots * hi) >= 64) return (int)hi;      // tail round <= 1.5 % whatever the choice
     int64_t best = hi;
     double best_cost = 1e30;
     for (int64_t ppb = np < 64 ? np : 64; ppb >= lo; --ppb) {
         const int64_t wgs = ((np + ppb - 1) / ppb) * n_qgroups;
-        const int64_t rounds = (wgs + 255) / 256;
+        const int64_t rounds = (wgs + slots - 1) / slots;
         const double cost = (double)rounds * ((double)ppb + 16.0 / (double)ntiles);
         if (cost < best_cost) { best_cost = cost; best = ppb; }   // ties: the larger ppb (fewer workgroups)
     }
@@ -101,7 +101,7 @@ const char* evdr_last_fwd_kernel_name();
 
 // launches (defined in the .hip files; all enqueue on `stream` and return the launch status)
 hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& p, int nplanes, bool want_argmax, hipStream_t stream);
-hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes, bool want_argmax, int geom,
+hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, int nplanes, bool want_argmax, int geom,
                                     hipStream_t stream);
 hipError_t evdr_launch_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, uint32_t* tilemask,
                                   uint32_t* pageflags, hipStream_t stream);

@@ -106,10 +106,10 @@ __device__ __forceinline__ BlockWork block_work(const EvdrFwdParams& p) {
 }  // namespace evdr
 
 // Host side: queries per workgroup -> launch geometry shared by every forward kernel.
-static inline int64_t evdr_set_geometry(EvdrFwdParams& p, int queries_per_wg) {
+static inline int64_t evdr_set_geometry(EvdrFwdParams& p, int queries_per_wg, int wgs_per_cu = 1) {
     p.ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     p.n_qgroups = (p.nq + queries_per_wg - 1) / queries_per_wg;
-    p.pages_per_block = evdr_pages_per_block(p.np, p.n_qgroups, p.ntiles);
+    p.pages_per_block = evdr_pages_per_block(p.np, p.n_qgroups, p.ntiles, 256 * wgs_per_cu);
     if (const int v = evdr_pages_per_block_override(); v > 0)       // evdr_debug_set_pages_per_block (A/B experiments)
         p.pages_per_block = v < p.np ? v : p.np;
     p.n_chunks = (p.np + p.pages_per_block - 1) / p.pages_per_block;

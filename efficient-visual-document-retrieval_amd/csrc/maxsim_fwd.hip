@@ -34,12 +34,24 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
     p.ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     // more queries per wave = more MFMAs per LDS read, bounded by the 256 VGPRs of a wave at 2 waves per SIMD:
     // 32 per bf16 query, 64 per fp16 hi/lo query, a few more for the running argmax
-    int qw;
-    if (nplanes == 1 && !want_argmax) qw = (p.nq > 16) ? 4 : (p.nq > 8 ? 2 : 1);
-    else qw = (p.nq > 8) ? 2 : 1;
     const int variant = g_fwd_variant.load(std::memory_order_relaxed);   // 0 = default dispatch (evdr_debug_set_fwd_variant)
+    int qw, waves = 8;
+    if (nplanes == 1 && !want_argmax) {
+        qw = (p.nq > 16) ? 4 : (p.nq > 8 ? 2 : 1);
+        // 5-8 queries per launch (online retrieval): ONE workgroup of 8 waves leaves the matrix pipes idle around every
+        // stage barrier, and with one query per wave a stage is too short to amortise that (63 % MFMA-busy in cycles).  Two
+        // independent 4-wave workgroups per CU (80 KiB of LDS each, 4-tile stages) on different page chunks fill each other's
+        // gaps: -6..9 % time at 5-8 queries; the queries are packed two to a wave so that ONE workgroup still covers all of
+        // them and no page is fetched twice.  (No gain at 9-16 queries; at 1024 the same split doubles the L2 -> LDS traffic.)
+        if (p.nq > 4 && p.nq <= 8 && variant != 30 && p.ntiles >= 4) {
+            waves = 4;
+            qw = 2;
+        }
+    } else {
+        qw = (p.nq > 8) ? 2 : 1;
+    }
     // HBM-bound launches (a handful of queries) want the refill in flight as early as possible: +3 % at 1-4 queries;
     // everything else hides the refill's address work under MFMAs: +2..4 %
     p.inblock_refill = p.nq > 4 ? 1 : 0;
-    return evdr_launch_maxsim_fwd16(p, qw, nplanes, want_argmax, variant, stream);
+    return evdr_launch_maxsim_fwd16(p, qw, waves, nplanes, want_argmax, variant, stream);
 }

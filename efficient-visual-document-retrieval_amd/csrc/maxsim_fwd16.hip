@@ -350,14 +350,14 @@ __device__ __forceinline__ void xgroup_argmax(float& v, int& idx) {
     }
 }
 
-template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
-__global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, int WAVES = 8>
+__global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
     using frag = typename FragOf<NPL>::type;
-    constexpr int WAVES = 8;
+    static_assert(WAVES == 8 || (WAVES == 4 && !BAL), "8 waves (one workgroup per CU) or 4 (two independent workgroups per CU)");
     constexpr int TILE_B = NPL * TILE_BYTES;              // planes of one tile are adjacent 8-KiB images
     constexpr int SLOT_TILES = ST + 1;                    // a ring slot holds one tile more than a stage's ST ...
     constexpr int STAGE_BYTES = SLOT_TILES * TILE_B;
-    constexpr int G = ST * NPL;                           // LDS-DMA pieces per wave per stage (8 pieces per tile and plane)
+    constexpr int G = ST * NPL * 8 / WAVES;               // LDS-DMA pieces per wave per stage (8 pieces per tile and plane)
     // plane products (A = page plane, B = query plane), smaller magnitude first
     constexpr int NPROD = (NPL == 1) ? 1 : 3;
     constexpr int PA[3] = {NPL - 1, 0, 0};
@@ -477,14 +477,18 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
     // the extra (ST-th) tile of an extended last stage: piece `wave` of each plane of that tile, always clamped
     auto issue_extra = [&](int pgi, int k, int thi, int slot) {
         if (!(ext && k == spp - 1) || thi < k * ST + ST) return;
-        const int row0 = (k * ST + ST) * EVDR_TILE_PATCHES + wave * 4;
-        const int rbase = min(row0, p.lp - 1);
-        const uint32_t voff = ((voff0 ^ ((uint32_t)(wave & 3) << 6)) & 0xFFu) + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            const uint16_t* sb = p.P + (int64_t)pl * p.p_plane_stride + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
-            lds_dma_16B_sbase(sb, voff,
-                              __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + ST * TILE_B + pl * TILE_BYTES + wave * 1024));
+        for (int pc = 0; pc < 8 / WAVES; ++pc) {
+            const int piece = wave + pc * WAVES;
+            const int row0 = (k * ST + ST) * EVDR_TILE_PATCHES + piece * 4;
+            const int rbase = min(row0, p.lp - 1);
+            const uint32_t voff = ((voff0 ^ ((uint32_t)(piece & 3) << 6)) & 0xFFu) + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                const uint16_t* sb = p.P + (int64_t)pl * p.p_plane_stride + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
+                lds_dma_16B_sbase(sb, voff,
+                                  __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + ST * TILE_B + pl * TILE_BYTES + piece * 1024));
+            }
         }
     };
     auto issue_stage = [&](int pgi, int k, int tlo, int thi, int slot) {
@@ -544,10 +548,29 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
     // pbase: first patch index of the 16-patch half (uniform); the lane's accumulator i is patch pbase + 4g + i
     auto chains_full = [&](const frag (&a)[NPL][4], int pbase) {           // all 16 patches of the half valid
         const int pb = pbase + 4 * g;
+        if constexpr (NPL == 1 && QW <= 2) {
+            // one or two queries per wave: the 2 QW chains of a half-tile are issued INTERLEAVED (k-step outermost), so that
+            // consecutive MFMAs never depend on each other; with 8 chains (QW = 4) the other wave of the SIMD fills those
+            // slots and keeping one accumulator live at a time matters more (+4..5 % at 5-16 queries per launch)
+            f32x4v acc[QW][2];
 #pragma unroll
-        for (int j = 0; j < QW; ++j)
+            for (int j = 0; j < QW; ++j) acc[j][0] = acc[j][1] = f32x4v{0, 0, 0, 0};
 #pragma unroll
-            for (int t = 0; t < 2; ++t) fold(chain(a, j, t), j, t, pb);
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int j = 0; j < QW; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(a[0][s4], bq[j][0][t][s4], acc[j][t]);
+#pragma unroll
+            for (int j = 0; j < QW; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fold(acc[j][t], j, t, pb);
+        } else {
+#pragma unroll
+            for (int j = 0; j < QW; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fold(chain(a, j, t), j, t, pb);
+        }
     };
     auto chains_masked = [&](const frag (&a)[NPL][4], uint32_t bits, int pbase) {
         const int pb = pbase + 4 * g;
@@ -598,8 +621,9 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
             }
         }
     };
-    // cursor state is kept small (it lives in SGPRs across the MFMA block): page, stage and flag word; spans are re-derived
-    int npgi = 0, nk;                                   // fetch cursor: page, stage
+    // fetch cursor: page, stage, flag word of its page, and the base pointer of the stage (advanced by one stage stride
+    // inside a page, recomputed at a page change: no 64-bit multiply per stage)
+    int npgi = 0, nk;
     uint32_t npf = pageflags_c[pg0];
     // flag word of the page AFTER the fetch cursor's, loaded a whole page before it is needed: the first stage of the next
     // page is chosen from it, and a scalar-load latency in front of every page's first refill would sit on the critical
@@ -610,22 +634,28 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
         page_span(npf, nk, khi0, tlo0, thi0);
         issue_stage(0, nk, tlo0, thi0, 0);
     }
+    const uint16_t* fbase = stage_base(0, nk);
     if constexpr (DIAG) d_pro = stamp() - d_t0;
     const bool spread_ok = p.inblock_refill != 0;
     int slot = 0;
     bool page_open = true;                              // the compute cursor is at the first stage of its page
+    // per-page values of the compute cursor, decoded once when the page is opened
     uint32_t pflags = 0u;
+    int va = 0, vb = 0, first_masked = 0, khi = 0;
     while (npgi < npages) {
         // the compute cursor takes over the stage that was fetched last; the fetch cursor moves on
         const int pgi = npgi, k = nk;
         const int page = pg0 + pgi;
-        if (page_open) pflags = npf;
-        // range pages: [va, vb); pages with holes: va = vb = -1 (mask words decide)
-        const int va = (pflags & 4u) ? (int)((pflags >> 4) & 0xFFFu) : -1;
-        const int vb = (pflags & 4u) ? (int)(pflags >> 16) : -1;
-        // index torch.max reports for an all-masked page / where the -1e4 fill first appears
-        const int first_masked = (pflags & 4u) ? (va > 0 ? 0 : vb) : (int)(pflags >> 16);
+        const uint16_t* cbase = fbase;                  // this stage's rows (a refill that stays in the page starts from it)
         if (page_open) {
+            pflags = npf;
+            // range pages: [va, vb); pages with holes: va = vb = -1 (mask words decide)
+            va = (pflags & 4u) ? (int)((pflags >> 4) & 0xFFFu) : -1;
+            vb = (pflags & 4u) ? (int)(pflags >> 16) : -1;
+            // index torch.max reports for an all-masked page / where the -1e4 fill first appears
+            first_masked = (pflags & 4u) ? (va > 0 ? 0 : vb) : (int)(pflags >> 16);
+            int klo, tlo, thi;
+            page_span(pflags, klo, khi, tlo, thi);
 #pragma unroll
             for (int j = 0; j < QW; ++j) {
                 // NPL = 1: a masked patch inside [0, lp) puts -1e4 into the max right away; NPL = 2 works in scaled units and
@@ -634,21 +664,18 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                 ridx[j][0] = ridx[j][1] = (NPL == 1) ? first_masked : 0;
             }
         }
-        bool page_close;
-        {
-            int klo, khi, tlo, thi;
-            page_span(pflags, klo, khi, tlo, thi);
-            page_close = (k + 1 == khi);
-        }
+        const bool page_close = (k + 1 == khi);
         if (!page_close) {
             ++nk;
+            fbase = cbase + (int64_t)ST * EVDR_TILE_PATCHES * EVDR_D;
         } else {
             ++npgi;
             if (npgi < npages) {
                 npf = apf;
                 if (npgi + 1 < npages) apf = pageflags_c[pg0 + npgi + 1];
-                int khi, tlo, thi;
-                page_span(npf, nk, khi, tlo, thi);
+                int khi2, tlo, thi;
+                page_span(npf, nk, khi2, tlo, thi);
+                fbase = stage_base(npgi, nk);
             }
         }
         const bool refill = npgi < npages;
@@ -689,7 +716,7 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
             const bool spread = SPREAD && fast && next_full && spread_ok;
             // one base pointer for the whole next stage (two SGPRs), the tile window of its page, and which of this wave's G
             // pieces lie inside it
-            const uint16_t* nbase = stage_base(refill ? npgi : pgi, refill ? nk : k);
+            const uint16_t* nbase = fbase;
             const int nt0 = nk * ST;
             int ntlo = 0, nthi = -1;
             uint32_t want = 0u;
@@ -774,19 +801,29 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                             }
                         };
                         if constexpr (NPL == 1) {
-                            frag alo[NPL][4], ahi[NPL][4];
-                            load_half(alo, sbase, 0, 0);
-                            load_half(ahi, sbase, 0, 1);
+                            // Fragment prefetch distance in half-tiles.  A half-tile is 2 QW chains of 4 MFMAs: 512 cycles of
+                            // matrix work at QW = 4, but only 128 at QW = 1 -- less than an LDS read takes to come back, so
+                            // with the one-half-ahead ping-pong of the QW = 4 instance a wave of the 1-16-query launches
+                            // stalled on every fragment (measured with the LDS-DMA removed: 30-40 cycles per MFMA).  The small
+                            // instances have the registers for a deeper ring of fragments: 4 halves ahead at QW = 1 and 2 (not with the argmax).
+                            constexpr int DEPTH = (QW <= 2 && !ARGMAX) ? 4 : 2;
+                            frag a[DEPTH][NPL][4];
 #pragma unroll
-                            for (int tis = 0; tis < ST; ++tis) {
-                                const int pbase = (t0 + tis) * EVDR_TILE_PATCHES;
-                                set_prio(2 * tis);
-                                if (HEAD && tis == 0) chains_masked(alo, headmask & 0xFFFFu, pbase); else chains_full(alo, pbase);
-                                if (tis + 1 < ST) load_half(alo, sbase, tis + 1, 0);
-                                if constexpr (SP) issue_piece(nbase, nt0, 0, 0, nslot, tis, std::true_type{});
-                                set_prio(2 * tis + 1);
-                                if (HEAD && tis == 0) chains_masked(ahi, headmask >> 16, pbase + 16); else chains_full(ahi, pbase + 16);
-                                if (tis + 1 < ST) load_half(ahi, sbase, tis + 1, 1);
+                            for (int h = 0; h < DEPTH; ++h) load_half(a[h], sbase, h >> 1, h & 1);
+#pragma unroll
+                            for (int h = 0; h < 2 * ST; ++h) {
+                                const int pbase = (t0 + (h >> 1)) * EVDR_TILE_PATCHES + 16 * (h & 1);
+                                set_prio(h);
+                                if (HEAD && h == 0) chains_masked(a[h % DEPTH], headmask & 0xFFFFu, pbase);
+                                else if (HEAD && h == 1) chains_masked(a[h % DEPTH], headmask >> 16, pbase);
+                                else chains_full(a[h % DEPTH], pbase);
+                                if (h + DEPTH < 2 * ST) load_half(a[h % DEPTH], sbase, (h + DEPTH) >> 1, (h + DEPTH) & 1);
+                                if constexpr (SP) {
+                                    if ((h & 1) == 0) {
+#pragma unroll
+                                        for (int e = 0; e < G / ST; ++e) issue_piece(nbase, nt0, 0, 0, nslot, (h >> 1) * (G / ST) + e, std::true_type{});
+                                    }
+                                }
                             }
                         } else {
                             // fp16 hi/lo planes: per 16-patch half, phase 1 = page-lo x query-hi on all 2 QW chains, phase 2 =
@@ -818,7 +855,7 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
                                 if constexpr (SP) {
                                     if ((h & 1) == 0) {
 #pragma unroll
-                                        for (int pl = 0; pl < NPL; ++pl) issue_piece(nbase, nt0, 0, 0, nslot, (h >> 1) * NPL + pl, std::true_type{});
+                                        for (int pl = 0; pl < G / ST; ++pl) issue_piece(nbase, nt0, 0, 0, nslot, (h >> 1) * (G / ST) + pl, std::true_type{});
                                     }
                                 }
 #pragma unroll
@@ -1018,22 +1055,22 @@ __global__ void __launch_bounds__(8 * 64, OCC) maxsim_fwd16s_kernel(const EvdrFw
     }
 }
 
-template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2>
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, int WAVES = 8>
 hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
     constexpr int LDS = NSTAGE * (ST + 1) * NPL * TILE_BYTES;
-    auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC>;
+    auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC, WAVES>;
     static uint64_t attr_devs = 0;
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
-    const int64_t blocks = evdr_set_geometry(p, 8 * QW);
+    const int64_t blocks = evdr_set_geometry(p, WAVES * QW, WAVES == 4 ? 2 : 1);
     static const char* const name = [] {
         static char buf[96];
-        snprintf(buf, sizeof(buf), "maxsim_fwd16s_kernel<%d,%d,%s,%d,%d,%s,%s,%d>", QW, NPL, ARGMAX ? "true" : "false", ST, NSTAGE,
-                 DIAG ? "true" : "false", BAL ? "true" : "false", OCC);
+        snprintf(buf, sizeof(buf), "maxsim_fwd16s_kernel<%d,%d,%s,%d,%d,%s,%s,%d,%d>", QW, NPL, ARGMAX ? "true" : "false", ST, NSTAGE,
+                 DIAG ? "true" : "false", BAL ? "true" : "false", OCC, WAVES);
         return (const char*)buf;
     }();
     evdr_note_fwd_kernel(name);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(8 * 64), LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WAVES * 64), LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -1068,7 +1105,7 @@ unsigned long long* evdr_experiment_dbg_buffer() { return g_dbg_buffer; }
 extern "C" void evdr_experiment_set_dbg_buffer(void* dev_ptr) { g_dbg_buffer = (unsigned long long*)dev_ptr; }
 #endif
 
-hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes, bool want_argmax, int geom, hipStream_t stream) {
+hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, int nplanes, bool want_argmax, int geom, hipStream_t stream) {
     const int ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     if (nplanes == 2) {
         // 16-KiB tiles: 4-tile stages (2 x 5 x 16 KiB = all 160 KiB of LDS) or 3-tile stages, whichever sends fewer FULL tiles
@@ -1101,6 +1138,8 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int nplanes,
     }
 #endif
     if (geom == 2 && ntiles >= 8 && qw == 4) return launch16s<4, 1, false, 8, 2, false, false>(p, stream);   // A/B: no priority schedule
+    if (waves == 4 && geom != 1)                          // two independent 4-wave workgroups per CU, 4-tile stages, 2 queries per wave
+        return launch16s<2, 1, false, 4, 2, false, false, 2, 4>(p, stream);
     if ((geom != 1 && ntiles >= 8) || p.per_token) {
         if (qw == 4) return launch16s<4, 1, false, 8, 2, false, true>(p, stream);
         if (qw == 2) return launch16s<2, 1, false, 8, 2, false, true>(p, stream);
