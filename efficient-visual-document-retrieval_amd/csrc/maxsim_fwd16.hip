@@ -851,6 +851,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                                     for (int j = 0; j < QW; ++j)
 #pragma unroll
                                         for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(al[s4], bq[j][0][t][s4], acc[j][t]);
+                                asm volatile("" ::: "memory");
                                 if (h + 1 < 2 * ST) load_plane(al, h + 1, 1);
                                 if constexpr (SP) {
                                     if ((h & 1) == 0) {
@@ -870,6 +871,10 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                                     for (int j = 0; j < QW; ++j)
 #pragma unroll
                                         for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][0][t][s4], acc[j][t]);
+                                // the next half's hi-plane fragments go into the registers the last product just released: the
+                                // LDS reads must not be hoisted above it (the scheduler did, and paid with spills INSIDE the block,
+                                // whose scratch reloads wait on vmcnt -- i.e. on the LDS-DMA refill in flight)
+                                asm volatile("" ::: "memory");
                                 if (h + 1 < 2 * ST) load_plane(ah, h + 1, 0);
                                 const int pb = (t0 + (h >> 1)) * EVDR_TILE_PATCHES + 16 * (h & 1) + 4 * g;
 #pragma unroll
