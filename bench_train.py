@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--only", type=str, default="", help="comma list of modes to run (default: all)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     import evdr_amd  # noqa: F401
     from evdr_amd import driver
@@ -105,10 +106,84 @@ def main():
     for kind in kinds:
         ms, loss = run(kind)
         res[kind] = {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "last_loss": loss}
-    print(json.dumps({"metric": "InfoNCE-distillation step time", "unit": "ms/step", "higher_is_better": False,
+
+    # ---- roofline of each dominant kernel of the fused step: HIP events around the launch on torch's current stream (the
+    # stream the ctypes wrappers launch on), algorithmic work from the shapes
+    from evdr_amd import _lib as L, ops
+    Qb, qmb = Qall[:B].contiguous(), qmall[:B]
+    teacher = driver.TeacherScorer(Pt, pmt)
+    student = driver.FusedStudent(Pbar0.clone(), pms, lr=1e-3, weight_decay=1e-2)
+    sc_s, arg = student.scores(Qb, qmb)
+    gscore = torch.randn_like(sc_s) * 1e-2
+    qpl, qam = ops.split_f32(Qb)
+    spl, sam = ops.l2norm_split(student.x, student.pmask, 1e-12)
+
+    def timed(fn, reps=30):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def kern():
+        return L.load().evdr_last_fwd_kernel().decode()
+
+    t_ms = timed(lambda: ops.maxsim_forward_prepared(qpl, qam, teacher.corpus.planes, teacher.corpus.amax, qmb, teacher.corpus.tilemask,
+                                                     teacher.corpus.pageflags))
+    t_kernel = kern()
+    s_ms = timed(lambda: ops.maxsim_forward_prepared(qpl, qam, spl, sam, qmb, student.tilemask, student.pageflags, want_argmax=True))
+    s_kernel = kern()
+    u_ms = timed(lambda: ops.maxsim_backward_adamw(gscore, Qb, qmb, student.pmask, arg, student.x, student.exp_avg, student.exp_avg_sq,
+                                                   1e-3, (0.9, 0.999), 1e-8, 1e-2, 1, 1e-12))
+    MFMA_F16_PEAK, HBM_PEAK = 2500.0, 8000.0          # TFLOP/s dense fp16/bf16, GB/s (MI355X_MICROARCH.md "Chip-level parameters")
+    plane_products = 3                                 # lo*hi + hi*lo + hi*hi per fp32 product (csrc/maxsim_fwd16.hip)
+    t_flop = 2.0 * B * N * Lq * Lt * D * plane_products
+    s_flop = 2.0 * B * N * Lq * Ls * D * plane_products
+    u_bytes = N * Ls * D * 4 * 6 + B * N * Lq * 2 + B * N * 4       # x, exp_avg, exp_avg_sq read + written; argmax and g read
+    roof = [
+        {"kernel": t_kernel, "role": "teacher forward (fp32 as fp16 hi/lo planes, 3 MFMA products)", "bound": "mfma", "kernel_ms": t_ms,
+         "achieved": t_flop / t_ms / 1e9, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s", "frac": t_flop / t_ms / 1e9 / MFMA_F16_PEAK,
+         "algorithmic_flop_per_launch": t_flop, "fp32_equivalent_tflops": t_flop / plane_products / t_ms / 1e9},
+        {"kernel": s_kernel, "role": "student forward + argmax", "bound": "mfma", "kernel_ms": s_ms,
+         "achieved": s_flop / s_ms / 1e9, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s", "frac": s_flop / s_ms / 1e9 / MFMA_F16_PEAK,
+         "algorithmic_flop_per_launch": s_flop, "fp32_equivalent_tflops": s_flop / plane_products / s_ms / 1e9},
+        {"kernel": "maxsim_bwd_kernel<128,1024,true>", "role": "MaxSim backward gather + l2-normalise backward + AdamW, in place", "bound": "hbm",
+         "kernel_ms": u_ms, "achieved": u_bytes / u_ms / 1e6, "peak": HBM_PEAK, "unit": "GB/s", "frac": u_bytes / u_ms / 1e6 / HBM_PEAK,
+         "algorithmic_bytes_per_launch": u_bytes},
+    ]
+
+    # ---- CPU baseline: the oracle's restatement of the reference step (mainv2_iter_distill_infonce.py:269-292) on the host
+    # cores, same shapes (a reported baseline, not a target)
+    cpu = None
+    if not a.no_cpu_baseline:
+        import bench as HB
+        from oracle import maxsim_oracle as O
+        cores = HB.host_cores()
+        torch.set_num_threads(cores)
+        Qc, qmc, Ptc, pmtc, Pbc, pmsc = Qb.cpu(), qmb.cpu(), Pt.cpu(), pmt.cpu(), Pbar0.cpu(), pms.cpu()
+        O.distill_train_step(Qc[:4], qmc[:4], Ptc[:32], pmtc[:32], Pbc[:32], pmsc[:32], 0.1, 1e-3, 1e-2)      # warm the thread pool
+        t0 = time.perf_counter()
+        n_cpu = 2
+        for _ in range(n_cpu):
+            loss_c = O.distill_train_step(Qc, qmc, Ptc, pmtc, Pbc, pmsc, 0.1, 1e-3, 1e-2)[0]
+        dt = (time.perf_counter() - t0) / n_cpu
+        cpu = {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+               "sample": f"{n_cpu} full steps at the same shape (B={B}, N={N}, teacher {Lt}, student {Ls} patches), torch fp32 CPU, "
+                         f"{dt:.2f} s per step, {cores} threads", "loss": loss_c}
+
+    head = "fused" if "fused" in res else (kinds[0] if kinds else None)
+    print(json.dumps({"metric": "InfoNCE-distillation steps/sec (mainv2_iter_distill_infonce.py train_one_step)",
+                      "value": res[head]["steps_per_sec"] if head else None, "unit": "steps/s", "n_gpus": 1, "higher_is_better": True,
+                      "ms_per_step": res[head]["ms_per_step"] if head else None, "mode": head, "dtype": "f32 (fp16 hi/lo split MFMA)",
+                      "data": "synthetic", "vs_baseline": None,
                       "config": {"workload": "mainv2_iter_distill_infonce step (BASELINE.json configs[4])", "pages": N,
-                                 "batch_queries": B, "teacher_patches": Lt, "student_patches": Ls, "dtype": "fp32 (fp16 hi/lo split MFMA)"},
-                      "results": res}))
+                                 "batch_queries": B, "teacher_patches": Lt, "student_patches": Ls, "steps": a.steps, "warmup": a.warmup},
+                      "results": res, "roofline": roof, "cpu_baseline": cpu}))
 
 
 if __name__ == "__main__":

@@ -45,6 +45,7 @@ class PageCorpus:
             raise RuntimeError("planes must be dense in their last two dims")
         self.p_stride, self.p_plane_stride = int(planes.stride(1)), int(planes.stride(0))
         self.device = planes.device
+        self._ws: Optional[torch.Tensor] = None       # score workspace of topk(), kept between calls (410 MB at 1024 x 100k)
 
     @classmethod
     def from_tensor(cls, P: torch.Tensor, pmask: Optional[torch.Tensor] = None, idx_base: int = 0) -> "PageCorpus":
@@ -69,8 +70,10 @@ class PageCorpus:
         return ops.split_f32(Q)
 
     def score(self, Q: torch.Tensor, qmask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              out_col: int = 0) -> torch.Tensor:
-        """(nq, n_pages) fp32 scores of this shard; with `out` given, written into out[:, out_col:out_col+n_pages]."""
+              out_col: int = 0, qplanes=None) -> torch.Tensor:
+        """(nq, n_pages) fp32 scores of this shard; with `out` given, written into out[:, out_col:out_col+n_pages].
+        `qplanes` = (planes, absmax word) of Q from `ops.split_f32`, when the caller has split the batch already (a training
+        step scores the same queries against teacher and student)."""
         dev = ops._require_cuda(Q)
         nq, lq, _ = Q.shape
         if out is None:
@@ -79,7 +82,7 @@ class PageCorpus:
         view = out[:, out_col:out_col + self.n_pages]
         if nq == 0 or self.n_pages == 0:
             return view
-        qp, qamax = self._query_planes(Q)
+        qp, qamax = qplanes if (qplanes is not None and self.nplanes == 2) else self._query_planes(Q)
         ops.maxsim_forward_prepared(qp, qamax, self.planes, self.amax, qmask, self.tilemask, self.pageflags, out=out,
                                     out_col=out_col)
         return view
@@ -99,7 +102,10 @@ class PageCorpus:
         qp, qamax = self._query_planes(Q)
         qm = ops._mask_u8(qmask, (nq, lq), dev)
         lib = L.load()
-        ws = ops.workspace(lib.evdr_maxsim_topk_workspace(nq, self.n_pages), dev)
+        need = lib.evdr_maxsim_topk_workspace(nq, self.n_pages)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = ops.workspace(need, dev)       # allocated once per (corpus, batch size), not per search
+        ws = self._ws
         with torch.cuda.device(dev):
             L.check(lib.evdr_maxsim_topk(
                 L.ptr(qp), L.ptr(self.planes), L.ptr(qm), L.ptr(self.tilemask), L.ptr(self.pageflags),

@@ -49,16 +49,16 @@ class TeacherScorer:
             self.have = np.zeros(cache_size, dtype=bool)
 
     @torch.no_grad()
-    def scores(self, Qb: torch.Tensor, qmb: torch.Tensor, qidx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def scores(self, Qb: torch.Tensor, qmb: torch.Tensor, qidx: Optional[torch.Tensor] = None, qplanes=None) -> torch.Tensor:
         """Teacher scores of the batch; with a cache and the batch's dataset indices `qidx` (a host tensor, as the
         DataLoader hands them out) a pseudo-query is scored once per run -- the teacher is frozen, so the cached rows are
         the same numbers (mainv2_iter_distill_infonce.py:282-283 recomputes them every epoch)."""
         if self.cache is None or qidx is None:
-            return self.corpus.score(Qb.float(), qmb)
+            return self.corpus.score(Qb.float(), qmb, qplanes=qplanes)
         idx_host = qidx.detach().cpu().numpy().astype(np.int64)
         idx_dev = qidx.to(self.cache.device, non_blocking=True)
         if not self.have[idx_host].all():
-            self.cache[idx_dev] = self.corpus.score(Qb.float(), qmb)
+            self.cache[idx_dev] = self.corpus.score(Qb.float(), qmb, qplanes=qplanes)
             self.have[idx_host] = True
         return self.cache[idx_dev]
 
@@ -362,11 +362,11 @@ class FusedStudent:
     def normalized(self) -> torch.Tensor:
         return ops.l2norm_forward(self.x, self.pmask, self.l2_eps)[0]
 
-    def scores(self, Qb, qmb) -> Tuple[torch.Tensor, torch.Tensor]:
+    def scores(self, Qb, qmb, qplanes=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Student scores (B, n_pages) and the argmax the update needs.  l2_normalize(Pbar * pmask) lands directly in the
-        scorer's fp16 hi/lo planes (no fp32 copy, no absmax/split pass)."""
+        scorer's fp16 hi/lo planes (no fp32 copy, no absmax/split pass).  `qplanes`: the batch's planes if already split."""
         pplanes, pamax = ops.l2norm_split(self.x, self.pmask, self.l2_eps, pageflags=self.pageflags)   # a diverged page scores NaN
-        qplanes, qamax = ops.split_f32(Qb)
+        qplanes, qamax = qplanes if qplanes is not None else ops.split_f32(Qb)
         return ops.maxsim_forward_prepared(qplanes, qamax, pplanes, pamax, qmb, self.tilemask, self.pageflags,
                                            want_argmax=True)
 
@@ -378,10 +378,10 @@ class FusedStudent:
         ops.maxsim_backward_adamw(dscore, Qb, qmb, self.pmask, arg, self.x, self.exp_avg, self.exp_avg_sq, self.lr,
                                   self.betas, self.eps, self.weight_decay, self.steps, self.l2_eps, state=state)
 
-    def update(self, Qb, qmb, sc_t, temp: float, state: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def update(self, Qb, qmb, sc_t, temp: float, state: Optional[torch.Tensor] = None, qplanes=None) -> torch.Tensor:
         """One step given the teacher scores; returns the loss as a device scalar (no host sync).  With `state` (a
         device-side step counter, ops.adamw_state) nothing in the step depends on a host scalar: graph-capturable."""
-        sc_s, arg = self.scores(Qb, qmb)
+        sc_s, arg = self.scores(Qb, qmb, qplanes)
         loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True)
         self.apply(dscore, Qb, qmb, arg, state)
         return loss
@@ -408,8 +408,9 @@ class GraphedStep:
         self.state = ops.adamw_state(dev)
 
         def body():
-            sc_t = self.sc_t if teacher is None else teacher.corpus.score(self.Qb, self.qmb)
-            return student.update(self.Qb, self.qmb, sc_t, temp, state=self.state)
+            qplanes = ops.split_f32(self.Qb)                         # once per step, shared by teacher and student
+            sc_t = self.sc_t if teacher is None else teacher.corpus.score(self.Qb, self.qmb, qplanes=qplanes)
+            return student.update(self.Qb, self.qmb, sc_t, temp, state=self.state, qplanes=qplanes)
 
         # warm-up on a side stream (lazy kernel attributes, allocator pools), then restore the parameters it touched
         keep = [t.clone() for t in (student.x, student.exp_avg, student.exp_avg_sq)]
@@ -445,9 +446,10 @@ class GraphedStep:
 def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStudent, temp: float,
                          qidx: Optional[torch.Tensor] = None) -> float:
     device = student.x.device
-    Qb = Qb.to(device, non_blocking=True)
+    Qb = Qb.to(device, non_blocking=True).float()
     qmb = qmb.to(device, non_blocking=True)
-    return float(student.update(Qb, qmb, teacher.scores(Qb, qmb, qidx), temp).item())
+    qplanes = ops.split_f32(Qb)                                      # once per step, shared by teacher and student
+    return float(student.update(Qb, qmb, teacher.scores(Qb, qmb, qidx, qplanes=qplanes), temp, qplanes=qplanes).item())
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -501,8 +503,9 @@ def sharded_fused_train_one_step(Qb, qmb, teacher_shard: "TeacherScorer", studen
     qmb = qmb.to(device, non_blocking=True)
     rank = dist.get_rank(group)
     lo = int(sum(shard_sizes[:rank]))
-    sc_s_local, arg = student_shard.scores(Qb, qmb)
-    sc_t = gather_columns(teacher_shard.scores(Qb, qmb, qidx), tuple(shard_sizes), group)
+    qplanes = ops.split_f32(Qb)
+    sc_s_local, arg = student_shard.scores(Qb, qmb, qplanes)
+    sc_t = gather_columns(teacher_shard.scores(Qb, qmb, qidx, qplanes=qplanes), tuple(shard_sizes), group)
     sc_s = gather_columns(sc_s_local, tuple(shard_sizes), group)
     loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True)
     student_shard.apply(dscore[:, lo: lo + int(shard_sizes[rank])].contiguous(), Qb, qmb, arg)
