@@ -42,6 +42,22 @@ __device__ __forceinline__ void lds_dma_16B_sbase(const void* sbase, uint32_t vo
         : "memory");
 }
 
+// The same with the non-temporal cache policy: for corpus bytes that exactly ONE workgroup reads exactly once (a launch with a
+// single query group: 1-32 queries): they need no place in L2 / Infinity Cache, and the stream lands sooner
+// (MI355X_MICROARCH.md "nt-weights": issued -> landed -18 %).  Never when several query groups re-read a page chunk from L2.
+__device__ __forceinline__ void lds_dma_16B_sbase_nt(const void* sbase, uint32_t voff, uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %2 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_base)
+        : "memory");
+}
+
 // counted wait on the vector-memory queue (loads, stores and LDS-DMA count together, in issue order)
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

@@ -350,7 +350,7 @@ __device__ __forceinline__ void xgroup_argmax(float& v, int& idx) {
     }
 }
 
-template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, int WAVES = 8>
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, int WAVES = 8, bool NT = false>
 __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
     using frag = typename FragOf<NPL>::type;
     static_assert(WAVES == 8 || (WAVES == 4 && !BAL), "8 waves (one workgroup per CU) or 4 (two independent workgroups per CU)");
@@ -471,8 +471,8 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
         uint32_t voff = voff0 ^ ((uint32_t)(piece & 3) << 6);
         if (!KNOWN_FULL && row0 + 3 >= p.lp)                                         // uniform: only a page's tail tile
             voff = (voff & 0xFFu) + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - min(row0, p.lp - 1)) * 256u;
-        lds_dma_16B_sbase(sb, voff,
-                          __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + tis * TILE_B + pl * TILE_BYTES + piece * 1024));
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + tis * TILE_B + pl * TILE_BYTES + piece * 1024);
+        if constexpr (NT) lds_dma_16B_sbase_nt(sb, voff, dst); else lds_dma_16B_sbase(sb, voff, dst);
     };
     // the extra (ST-th) tile of an extended last stage: piece `wave` of each plane of that tile, always clamped
     auto issue_extra = [&](int pgi, int k, int thi, int slot) {
@@ -1060,18 +1060,18 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     }
 }
 
-template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, int WAVES = 8>
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, int WAVES = 8, bool NT = false>
 hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
     constexpr int LDS = NSTAGE * (ST + 1) * NPL * TILE_BYTES;
-    auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC, WAVES>;
+    auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC, WAVES, NT>;
     static uint64_t attr_devs = 0;
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, WAVES * QW, WAVES == 4 ? 2 : 1);
     static const char* const name = [] {
         static char buf[96];
-        snprintf(buf, sizeof(buf), "maxsim_fwd16s_kernel<%d,%d,%s,%d,%d,%s,%s,%d,%d>", QW, NPL, ARGMAX ? "true" : "false", ST, NSTAGE,
-                 DIAG ? "true" : "false", BAL ? "true" : "false", OCC, WAVES);
+        snprintf(buf, sizeof(buf), "maxsim_fwd16s_kernel<%d,%d,%s,%d,%d,%s,%s,%d,%d,%s>", QW, NPL, ARGMAX ? "true" : "false", ST, NSTAGE,
+                 DIAG ? "true" : "false", BAL ? "true" : "false", OCC, WAVES, NT ? "true" : "false");
         return (const char*)buf;
     }();
     evdr_note_fwd_kernel(name);
@@ -1143,11 +1143,15 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, i
     }
 #endif
     if (geom == 2 && ntiles >= 8 && qw == 4) return launch16s<4, 1, false, 8, 2, false, false>(p, stream);   // A/B: no priority schedule
+    // launches of ONE query group (<= 8 queries here): every page is read by exactly one workgroup, exactly once -> the corpus
+    // stream uses the non-temporal policy (NT instances; geom 31 = A/B without it)
+    const bool nt = geom != 31;
     if (waves == 4 && geom != 1)                          // two independent 4-wave workgroups per CU, 4-tile stages, 2 queries per wave
-        return launch16s<2, 1, false, 4, 2, false, false, 2, 4>(p, stream);
+        return nt ? launch16s<2, 1, false, 4, 2, false, false, 2, 4, true>(p, stream) : launch16s<2, 1, false, 4, 2, false, false, 2, 4>(p, stream);
     if ((geom != 1 && ntiles >= 8) || p.per_token) {
         if (qw == 4) return launch16s<4, 1, false, 8, 2, false, true>(p, stream);
         if (qw == 2) return launch16s<2, 1, false, 8, 2, false, true>(p, stream);
+        if (nt && p.nq <= 8 && !p.per_token) return launch16s<1, 1, false, 8, 2, false, true, 2, 8, true>(p, stream);
         return launch16s<1, 1, false, 8, 2, false, true>(p, stream);
     }
     if (qw == 4) return launch16<4, 8, 4, 3>(p, stream);
