@@ -37,7 +37,9 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
     const int variant = g_fwd_variant.load(std::memory_order_relaxed);   // 0 = default dispatch (evdr_debug_set_fwd_variant)
     int qw, waves = 8;
     if (nplanes == 1 && !want_argmax) {
-        qw = (p.nq > 16) ? 4 : (p.nq > 8 ? 2 : 1);
+        // 17-24 queries: three per wave, so that all eight waves work (with four, two of them idle and the launch takes
+        // as long as one of 32 queries)
+        qw = (p.nq > 24) ? 4 : (p.nq > 16 ? 3 : (p.nq > 8 ? 2 : 1));
         // 5-8 queries per launch (online retrieval): ONE workgroup of 8 waves leaves the matrix pipes idle around every
         // stage barrier, and with one query per wave a stage is too short to amortise that (63 % MFMA-busy in cycles).  Two
         // independent 4-wave workgroups per CU (80 KiB of LDS each, 4-tile stages) on different page chunks fill each other's

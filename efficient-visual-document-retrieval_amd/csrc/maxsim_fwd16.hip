@@ -1150,11 +1150,12 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, i
         return nt ? launch16s<2, 1, false, 4, 2, false, false, 2, 4, true>(p, stream) : launch16s<2, 1, false, 4, 2, false, false, 2, 4>(p, stream);
     if ((geom != 1 && ntiles >= 8) || p.per_token) {
         if (qw == 4) return launch16s<4, 1, false, 8, 2, false, true>(p, stream);
+        if (qw == 3) return launch16s<3, 1, false, 8, 2, false, true>(p, stream);
         if (qw == 2) return launch16s<2, 1, false, 8, 2, false, true>(p, stream);
         if (nt && p.nq <= 8 && !p.per_token) return launch16s<1, 1, false, 8, 2, false, true, 2, 8, true>(p, stream);
         return launch16s<1, 1, false, 8, 2, false, true>(p, stream);
     }
-    if (qw == 4) return launch16<4, 8, 4, 3>(p, stream);
+    if (qw >= 3) return launch16<4, 8, 4, 3>(p, stream);
     if (qw == 2) return launch16<2, 8, 4, 3>(p, stream);
     return launch16<1, 8, 4, 3>(p, stream);
 }

@@ -225,3 +225,20 @@ def test_metrics_vs_sklearn(pkg):
     for k, vals in want_ndcg.items():
         assert got["NDCG"][f"NDCG@{k}"] == pytest.approx(float(np.mean(vals)), abs=1.1e-5), k
     assert got["mAP"]["MAP@50"] == pytest.approx(float(np.mean(want_map)), abs=1.1e-5)
+
+
+def test_results_from_topk_uses_the_tie_completion():
+    """Rows whose k-th score is tied beyond the device cut carry ALL candidates with a score >= the k-th one
+    (ops.topk_with_ties); the metric then ranks them by trec_eval's rule (docid descending) like the reference's all-pairs
+    dict does -- here: 6 pages, k = 2, three pages tied at the cut."""
+    from evdr_amd.evaluator.metrics import evaluate, results_from_topk
+    scores = np.array([[3.0, 1.0, 2.0, 2.0, 2.0, 0.5]], dtype=np.float32)
+    docids = ["a", "b", "c", "d", "e", "f"]
+    ts, ti = np.array([[3.0, 2.0]], dtype=np.float32), np.array([[0, 2]], dtype=np.int32)       # device order: index ascending
+    extra = {0: (np.array([0, 2, 3, 4]), np.array([3.0, 2.0, 2.0, 2.0], dtype=np.float32))}
+    qrels = {"q": {"e": 1}}                                                                     # trec_eval puts "e" at rank 2
+    allpairs = {"q": {d: float(s) for d, s in zip(docids, scores[0])}}
+    want = evaluate(qrels, allpairs, [1, 2])
+    assert evaluate(qrels, results_from_topk(ts, ti, ["q"], docids, extra=extra), [1, 2]) == want
+    assert want["Recall"]["Recall@2"] == 1.0
+    assert evaluate(qrels, results_from_topk(ts, ti, ["q"], docids), [1, 2])["Recall"]["Recall@2"] == 0.0   # the bare cut misses it
