@@ -37,9 +37,16 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
     const int variant = g_fwd_variant.load(std::memory_order_relaxed);   // 0 = default dispatch (evdr_debug_set_fwd_variant)
     int qw, waves = 8;
     if (nplanes == 1 && !want_argmax) {
-        // 17-24 queries: three per wave, so that all eight waves work (with four, two of them idle and the launch takes
-        // as long as one of 32 queries)
-        qw = (p.nq > 24) ? 4 : (p.nq > 16 ? 3 : (p.nq > 8 ? 2 : 1));
+        // Queries per wave from the batch size: a workgroup covers 8 * qw queries, and a workgroup with idle waves takes as
+        // long as a full one.  So the batch is cut into ceil(nq / 32) query groups and qw is what ONE group needs per wave:
+        // 17-24 queries run three to a wave on all eight waves instead of four to a wave on six (-15..18 % time), 40 queries
+        // are two groups of 24 + 16 at three per wave instead of 32 + 8 at four.
+        {
+            const int groups = (p.nq + 31) / 32;
+            const int per_group = (p.nq + groups - 1) / groups;
+            qw = (per_group + 7) / 8;
+            qw = qw < 1 ? 1 : (qw > 4 ? 4 : qw);
+        }
         // 5-8 queries per launch (online retrieval): ONE workgroup of 8 waves leaves the matrix pipes idle around every
         // stage barrier, and with one query per wave a stage is too short to amortise that (63 % MFMA-busy in cycles).  Two
         // independent 4-wave workgroups per CU (80 KiB of LDS each, 4-tile stages) on different page chunks fill each other's
