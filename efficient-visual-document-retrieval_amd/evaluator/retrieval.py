@@ -62,11 +62,14 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
     if hit is not None and hit[0]() is not None and (pmask is None or hit[1]() is not None):
         _PREPARED.move_to_end(key)
         return hit[2]
-    planes, amax = ops.split_f32(P)
+    if P.dtype == torch.bfloat16:                      # scored as they are: only the packed masks and the non-finite scan are kept
+        planes, amax = P.contiguous()[None], None
+    else:
+        planes, amax = ops.split_f32(P)
     tilemask, pageflags = ops.pack_pmask(pmask, P.shape[0], P.shape[1], P.device)
     ops.flag_nonfinite(planes[0], pmask, pageflags)
     prep = (planes, amax, tilemask, pageflags)
-    nbytes = planes.numel() * planes.element_size()
+    nbytes = 0 if (P.dtype == torch.bfloat16 and P.is_contiguous()) else planes.numel() * planes.element_size()
     if nbytes <= _PREPARED_MAX_BYTES:
         drop = lambda _ref, key=key: _PREPARED.pop(key, None)          # the tensor died: free its planes right away
         _PREPARED[key] = (weakref.ref(P, drop), weakref.ref(pmask, drop) if pmask is not None else None, prep, nbytes)
@@ -82,12 +85,15 @@ class _MaxSimMasked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Q, P, qmask, pmask):
         need_dq, need_dp = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        both_bf16 = P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16
         frozen = (not need_dp and P.is_cuda and P.dim() == 3 and Q.dim() == 3 and P.shape[-1] == ops.D and Q.shape[-1] == ops.D
-                  and not (P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16) and P.shape[0] > 0 and P.shape[1] > 0
+                  and (both_bf16 or P.dtype != torch.bfloat16) and not (both_bf16 and need_dq)
+                  and P.shape[0] > 0 and P.shape[1] > 0
                   and Q.shape[0] > 0 and Q.shape[1] > 0 and P.shape[1] <= 65535 and Q.shape[1] <= 65535)
         if frozen:
+            # frozen pages: mask packing, the non-finite scan and (fp32) the plane split are done once per tensor
             planes, amax, tilemask, pageflags = _prepared_pages(P, pmask)
-            qplanes, qamax = ops.split_f32(Q)
+            qplanes, qamax = (Q.contiguous()[None], None) if both_bf16 else ops.split_f32(Q)
             out, arg = ops.maxsim_forward_prepared(qplanes, qamax, planes, amax, qmask, tilemask, pageflags,
                                                    want_argmax=need_dq)
         else:
