@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--queries", type=int, default=1024, help="queries per step")
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-regimes", action="store_true",
+                    help="skip the 1- and 8-query streaming launches (PMC passes aggregate over the launches they see)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse N>1 on a 1-GPU box)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -274,6 +276,27 @@ def main():
                 "kernel": kernel_symbol, "kernel_ms": k_ms,
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "algorithmic_bytes_per_launch": corpus.n_pages * LP * D * 2}
+
+    # ---- the other end of the roofline: few queries per pass stream the corpus from HBM (263 680 B per page, read once)
+    def stream_regime(nq_small):
+        Qs = Q[:nq_small].contiguous()
+        o = torch.empty((nq_small, corpus.n_pages), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            corpus.score(Qs, None, out=o)
+        torch.cuda.synchronize()
+        e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in e:
+            a.record()
+            corpus.score(Qs, None, out=o)
+            b.record()
+        torch.cuda.synchronize()
+        ms = min(a.elapsed_time(b) for a, b in e)
+        gbps = corpus.n_pages * LP * D * 2 / (ms * 1e-3) / 1e9
+        return {"queries_per_pass": nq_small, "kernel": L.load().evdr_last_fwd_kernel().decode(), "kernel_ms": ms, "bound": "hbm",
+                "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                "algorithmic_bytes_per_launch": corpus.n_pages * LP * D * 2,
+                "mfma_tflops": nq_small * corpus.n_pages * FLOP_PER_PAIR / (ms * 1e-3) / 1e12}
+    roofline["other_regimes"] = [stream_regime(1), stream_regime(8)] if (args.queries >= 8 and not args.no_other_regimes) else []
 
     # ---- quality on the planted queries (rank 0; uses the merged top-k of the last step)
     ndcg5 = None
