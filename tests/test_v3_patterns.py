@@ -82,3 +82,34 @@ def test_each_secondary_loss_drives_the_hip_backward(name):
     # gradient error of ~2e-6 / tau (3e-5 at tau = 0.07): atol scales with the gradient's magnitude, floor 1e-6
     want = res["oracle"][1].numpy()
     np.testing.assert_allclose(res["hip"][1].numpy(), want, atol=max(1e-6, 5e-5 * float(np.abs(want).max())), rtol=1e-5)
+
+
+def _run_loss_steps(be, golden, grad_atol):
+    """Each of the nine remaining single-loss scripts: loss value(s), Pbar.grad (strided sample + norm) and the parameters after
+    AdamW against what the reference's own train_one_step produced."""
+    z = golden("v3_loss_steps")
+    case = R.v3_case()
+    for tag, loss_fn in V.loss_steps(be).items():
+        out = V.step_with_loss(be, case, loss_fn)
+        main_key = f"{tag}__total_loss" if f"{tag}__total_loss" in z.files else f"{tag}__loss"
+        np.testing.assert_allclose(out["total_loss"], float(z[main_key]), rtol=1e-5, err_msg=tag)
+        for k, v in out.items():
+            if f"{tag}__{k}" in z.files and k not in ("total_loss",):
+                np.testing.assert_allclose(v, float(z[f"{tag}__{k}"]), rtol=1e-5, err_msg=f"{tag}:{k}")
+        g = out["grad"].cpu().numpy()
+        want = z[f"{tag}__grad_sample"]
+        # losses with a temperature tau turn the ~2e-6 score noise of the GPU sums into ~2e-6 / tau relative gradient noise
+        np.testing.assert_allclose(g[::2, ::2, ::2], want, atol=max(grad_atol, 5e-5 * float(np.abs(want).max())), rtol=1e-5, err_msg=tag)
+        np.testing.assert_allclose(np.linalg.norm(g.astype(np.float64)), float(z[f"{tag}__grad_norm"]), rtol=1e-4, err_msg=tag)
+        d = np.abs(out["param_after"].cpu().numpy()[::2, ::2, ::2] - z[f"{tag}__param_sample"])
+        big = np.abs(want) > 1e-6 * max(1.0, float(np.abs(want).max()) / 1e-2)
+        assert d[big].max() <= 2e-6 and d.max() < 2e-3, (tag, d[big].max(), d.max())
+
+
+def test_oracle_reproduces_the_nine_loss_steps(golden):
+    _run_loss_steps(V.oracle_backend(), golden, grad_atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_the_nine_loss_steps(golden):
+    _run_loss_steps(V.hip_backend(), golden, grad_atol=1e-6)

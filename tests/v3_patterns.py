@@ -15,7 +15,8 @@ def oracle_backend():
     from evdr_amd import criterion as C          # the (B, N) losses are plain torch and run on either device
     from oracle import maxsim_oracle as O
     return SimpleNamespace(score=lambda Q, P, qm, pm, chunk=64: O.maxsim_masked(Q, P, qm, pm, chunk_p=chunk), l2=O.l2_normalize,
-                           listwise=C.listwise_distillation_loss, preserve=C.score_preserving_loss, device="cpu")
+                           listwise=C.listwise_distillation_loss, preserve=C.score_preserving_loss,
+                           infonce=lambda s, t, temperature: O.infonce_distill(s, t, temperature), device="cpu")
 
 
 def hip_backend():
@@ -24,7 +25,7 @@ def hip_backend():
     from evdr_amd.evaluator.retrieval import score_multi_vector_masked
     from evdr_amd.utils.preprocess_data import l2_normalize
     return SimpleNamespace(score=score_multi_vector_masked, l2=l2_normalize, listwise=C.listwise_distillation_loss,
-                           preserve=C.score_preserving_loss, device="cuda:0")
+                           preserve=C.score_preserving_loss, infonce=C.infonce_distillation_loss, device="cuda:0")
 
 
 def setup(be, case):
@@ -130,3 +131,47 @@ def step_hardtoken(be, case):
     total = main + hp["lambda_aux"] * aux
     return _finish(total, opt, param, loss_main=float(main.item()), loss_aux=float(aux.item()), loss_list_aux=float(l_list_v.item()),
                    loss_score_aux=float(l_score_v.item()), q_virtual=qv, sc_t_v=sc_t_v, sc_s_v=sc_s_v.detach())
+
+
+# ---- the nine remaining single-step scripts: same step, different loss (tests/golden/make_golden_losses_steps.py) ------------
+def loss_steps(be):
+    """script tag -> (loss(sc_s, sc_t) -> (total, {name: value}), needs_teacher): the loss lines of
+    mainv2_iter_{lambda,linfo_distill,lipairwise,listwise,pairscore,ranknce,ranknet,score_preserve,super_infonce}.py"""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import criterion as C
+
+    def linfo(s, t):
+        a, b = C.listwise_distillation_loss(s, t, k=8, temperature=2.0), be.infonce(s, t, temperature=0.1)   # the HIP loss kernel on the GPU
+        return 1.0 * a + 0.5 * b, {"loss_list": a, "loss_info": b}
+
+    def lipair(s, t):
+        a, b = C.listwise_distillation_loss(s, t, k=8, temperature=2.0), C.pairwise_distillation_loss(s, t)
+        return 1.0 * a + 0.5 * b, {"loss_list": a, "loss_pair": b}
+
+    def pairscore(s, t):
+        a, b = C.pairwise_distillation_loss(s, t), C.score_preserving_loss(s, t)
+        return 1.0 * a + 0.5 * b, {"loss_pair": a, "loss_score": b}
+
+    pos = torch.tensor([3, 0, 15, 7, 7, 9])
+    single = lambda f: (lambda s, t: (f(s, t), {}))
+    return {
+        "lambda": single(lambda s, t: C.lambda_loss(s, t, alpha=1.0, eps=1e-6)),
+        "linfo_distill": linfo,
+        "lipairwise": lipair,
+        "listwise": single(lambda s, t: C.listwise_distillation_loss(s, t, k=8, temperature=2.0)),
+        "pairscore": pairscore,
+        "ranknce": single(lambda s, t: C.ranknce_loss(s, t, temperature=0.5, lambda_weight=0.7)),
+        "ranknet": single(lambda s, t: C.pairwise_distillation_loss(s, t)),
+        "score_preserve": single(lambda s, t: C.score_preserving_loss(s, t)),
+        "super_infonce": single(lambda s, t: C.infonce_supervised_loss(s, pos.to(s.device), temperature=0.07)),
+    }
+
+
+def step_with_loss(be, case, loss_fn):
+    Qb, qmb, Ptn, pmt, param, pms, opt, hp = setup(be, case)
+    Psb = be.l2(param * pms.unsqueeze(-1))
+    with torch.no_grad():
+        sc_t = be.score(Qb, Ptn, qmb, pmt, 64)
+    sc_s = be.score(Qb, Psb, qmb, pms, 64)
+    total, parts = loss_fn(sc_s, sc_t)
+    return _finish(total, opt, param, **{k: float(v.item()) for k, v in parts.items()})
