@@ -1,0 +1,34 @@
+"""One-off fuzz of the forward kernels against the oracle: many seeds of tests/test_gpu_random_sweep.py's case generator plus
+1030-patch range/hole layouts with random query counts.  usage: python scratch/fuzz_fwd.py <first_seed> <count>"""
+import os, sys, numpy as np, torch
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import evdr_amd
+from evdr_amd import ops
+from oracle import maxsim_oracle as O
+import test_gpu_random_sweep as T
+dev = "cuda:0"; s0, n = int(sys.argv[1]), int(sys.argv[2]); bad = 0
+torch.set_num_threads(16)
+for seed in range(s0, s0 + n):
+    Q, P, qm, pm = T._case(seed)
+    if seed % 3 == 0:                                   # long pages with range / hole layouts and random query counts
+        g = torch.Generator().manual_seed(seed)
+        nq = int(torch.randint(1, 45, (1,), generator=g)); npg = int(torch.randint(1, 20, (1,), generator=g)); lp = [1030, 1024, 1056, 993, 513][seed % 5]
+        Q = torch.nn.functional.normalize(torch.randn(nq, 32, 128, generator=g), dim=-1).bfloat16()
+        P = torch.nn.functional.normalize(torch.randn(npg, lp, 128, generator=g), dim=-1).bfloat16()
+        a = torch.randint(0, lp, (npg,), generator=g); b = torch.randint(0, lp + 1, (npg,), generator=g)
+        lo, hi = torch.minimum(a, b), torch.maximum(a, b)
+        ar = torch.arange(lp)[None, :]
+        pm = (ar >= lo[:, None]) & (ar < hi[:, None])
+        if seed % 2: pm[:, int(torch.randint(0, lp, (1,), generator=g))] = False      # one hole: mask words decide
+        qm = torch.rand(nq, 32, generator=g) > 0.2
+    want, warg = O.maxsim_masked_argmax(Q.float(), P.float(), qm, pm)
+    for am in (False, True):
+        for Qx, Px in ((Q, P), (Q.float(), P.float())):
+            s, arg = ops.maxsim_forward(Qx.to(dev), Px.to(dev), qm.to(dev), pm.to(dev), want_argmax=am)
+            err = (s.cpu() - want).abs().max().item()
+            ok = err < 1e-4 and (not am or torch.equal(arg.cpu().to(torch.int32) & 0xFFFF, warg.to(torch.int32)))
+            if not ok:
+                bad += 1; print(f"FAIL seed={seed} argmax={am} dtype={Qx.dtype} shape Q{tuple(Q.shape)} P{tuple(P.shape)} err={err:.3e}", flush=True)
+    if (seed - s0) % 50 == 49: print(f"... {seed - s0 + 1} seeds, {bad} failures", flush=True)
+print(f"done: {n} seeds, {bad} failures")
