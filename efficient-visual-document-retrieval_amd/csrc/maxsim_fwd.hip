@@ -47,14 +47,15 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
             qw = (per_group + 7) / 8;
             qw = qw < 1 ? 1 : (qw > 4 ? 4 : qw);
         }
-        // 5-8 queries per launch (online retrieval): ONE workgroup of 8 waves leaves the matrix pipes idle around every
+        // 3-12 queries per launch (online retrieval): ONE workgroup of 8 waves leaves the matrix pipes idle around every
         // stage barrier, and with one query per wave a stage is too short to amortise that (63 % MFMA-busy in cycles).  Two
         // independent 4-wave workgroups per CU (80 KiB of LDS each, 4-tile stages) on different page chunks fill each other's
-        // gaps: -6..9 % time at 5-8 queries; the queries are packed two to a wave so that ONE workgroup still covers all of
-        // them and no page is fetched twice.  (No gain at 9-16 queries; at 1024 the same split doubles the L2 -> LDS traffic.)
-        if (p.nq > 4 && p.nq <= 8 && variant != 30 && p.ntiles >= 4) {
+        // gaps: -6..13 % time at 3-4 queries (one per wave), -6..9 % at 5-8 (two per wave), -20 % at 9-12 (three per wave: with two on eight waves
+        // a quarter of the waves idled); ONE workgroup still covers all queries, so no page is fetched twice.  (No gain at
+        // 13-16 queries with four per wave; at 1024 queries the same split doubles the L2 -> LDS traffic.)
+        if (p.nq > 2 && p.nq <= 12 && variant != 30 && p.ntiles >= 4) {
             waves = 4;
-            qw = 2;
+            qw = (p.nq + 3) / 4;
         }
     } else {
         qw = (p.nq > 8) ? 2 : 1;

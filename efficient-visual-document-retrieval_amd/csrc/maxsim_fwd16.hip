@@ -1146,8 +1146,11 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, i
     // launches of ONE query group (<= 8 queries here): every page is read by exactly one workgroup, exactly once -> the corpus
     // stream uses the non-temporal policy (NT instances; geom 31 = A/B without it)
     const bool nt = geom != 31;
-    if (waves == 4 && geom != 1)                          // two independent 4-wave workgroups per CU, 4-tile stages, 2 queries per wave
+    if (waves == 4 && geom != 1) {                        // two independent 4-wave workgroups per CU, 4-tile stages, 2 or 3 queries per wave
+        if (qw == 3) return launch16s<3, 1, false, 4, 2, false, false, 2, 4, true>(p, stream);
+        if (qw == 1) return launch16s<1, 1, false, 4, 2, false, false, 2, 4, true>(p, stream);
         return nt ? launch16s<2, 1, false, 4, 2, false, false, 2, 4, true>(p, stream) : launch16s<2, 1, false, 4, 2, false, false, 2, 4>(p, stream);
+    }
     if ((geom != 1 && ntiles >= 8) || p.per_token) {
         if (qw == 4) return launch16s<4, 1, false, 8, 2, false, true>(p, stream);
         if (qw == 3) return launch16s<3, 1, false, 8, 2, false, true>(p, stream);
