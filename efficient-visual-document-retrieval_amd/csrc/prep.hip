@@ -138,45 +138,6 @@ __global__ void __launch_bounds__(256) split_h2_kernel(const float* __restrict__
     }
 }
 
-// Small tensors (a query batch: 32 x 32 rows): absmax and split in ONE launch of one workgroup instead of memset + absmax +
-// split -- three launches of a few microseconds each on a training step whose kernels take 0.5 ms.
-__global__ void __launch_bounds__(1024) split_small_kernel(const float* __restrict__ x, int64_t n8, uint32_t* __restrict__ amax_bits,
-                                                           _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
-    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-    __shared__ uint32_t wmax[16];
-    uint32_t m = 0;
-    for (int64_t i = threadIdx.x; i < n8; i += 1024) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + i * 8), v1 = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float f = (k < 4) ? v0[k & 3] : v1[k & 3];
-            const uint32_t b = __builtin_bit_cast(uint32_t, f) & 0x7FFFFFFFu;
-            if (b < 0x7F800000u) m = max(m, b);                   // finite elements only (see absmax_kernel)
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    m = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
-    if (threadIdx.x == 0) *amax_bits = m;
-    const int k = evdr_h2_shift(m);
-    for (int64_t i = threadIdx.x; i < n8; i += 1024) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + i * 8), v1 = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
-        f16x8 a, b;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float f = __builtin_ldexpf((j < 4) ? v0[j & 3] : v1[j & 3], k);
-            const _Float16 h = (_Float16)f;
-            a[j] = h;
-            b[j] = (_Float16)(f - (float)h);
-        }
-        *reinterpret_cast<f16x8*>(hi + i * 8) = a;
-        *reinterpret_cast<f16x8*>(lo + i * 8) = b;
-    }
-}
-
 // Stable compaction of the queries that have a valid token in [tok0, tok0 + 32): one workgroup, 256 queries per round.
 __global__ void __launch_bounds__(256) build_qlist_kernel(const uint8_t* __restrict__ qmask, int nq, int lq, int tok0,
                                                          int32_t* __restrict__ qlist, int32_t* __restrict__ qcount) {
@@ -238,11 +199,6 @@ hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes,
 // the same for pages: non-finite elements of valid patches are reported in `pageflags` (bit 3) on the way
 hipError_t evdr_launch_split_f32_pages(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, const uint8_t* rowmask,
                                        int64_t rows_per_page, uint32_t* pageflags, hipStream_t stream) {
-    if (pageflags == nullptr && rows > 0 && rows <= 4096) {        // a query batch: one launch
-        hipLaunchKernelGGL(split_small_kernel, dim3(1), dim3(1024), 0, stream, x, rows * (EVDR_D / 8), amax_bits, (_Float16*)planes,
-                           (_Float16*)planes + rows * EVDR_D);
-        return hipGetLastError();
-    }
     hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const int64_t n8 = rows * (EVDR_D / 8);
