@@ -3,8 +3,9 @@
 shape -- 32 queries x 32 tokens, N = 500 pages, teacher 1030 patches, student 206 patches (mf5), fp32 parameters,
 temperature 0.1, AdamW(lr 1e-3, wd 1e-2).  Reports ms/step of the drop-in functions used exactly like
 mainv2_iter_distill_infonce.py:269-292 ("call_pattern"), of the driver's resident-teacher step ("resident") and of
-the same with cached teacher scores ("cached"), of the fused student update ("fused", "fused_cached") and of its HIP-graph
-replay ("fused_graph", "fused_cached_graph"); `--eager` adds a plain torch restatement of the reference's four
+the same with cached teacher scores ("cached"), of the fused student update ("fused", "fused_cached"; "_nosync": the loss
+stays on the device and the host queues the next step without waiting) and of its HIP-graph replay ("fused_graph",
+"fused_cached_graph"); `--eager` adds a plain torch restatement of the reference's four
 ATen ops on the same GPU for context.  Not the driver's headline bench (that is bench.py)."""
 import argparse
 import json
@@ -57,7 +58,7 @@ def main():
     def run(kind):
         param = torch.nn.Parameter(Pbar0.clone())
         opt = torch.optim.AdamW([param], lr=1e-3, weight_decay=1e-2)
-        cached = kind in ("cached", "fused_cached", "fused_cached_graph")
+        cached = kind in ("cached", "fused_cached", "fused_cached_graph", "fused_cached_nosync")
         teacher = driver.TeacherScorer(Pt, pmt, cache_size=Qall.shape[0] if cached else 0) if kind not in ("call_pattern", "eager") else None
         student = driver.FusedStudent(Pbar0.clone(), pms, lr=1e-3, weight_decay=1e-2) if kind.startswith("fused") else None
         graphed = student.graphed(B, Lq, 0.1, None if cached else teacher) if kind.endswith("_graph") else None
@@ -73,6 +74,9 @@ def main():
                 return float(graphed(Qb, qmb, teacher.scores(Qb, qmb, idx)).item())
             if kind in ("fused", "fused_cached"):
                 return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached" else None)
+            if kind in ("fused_nosync", "fused_cached_nosync"):     # loss stays on the device: no host sync inside the timed loop
+                return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached_nosync" else None,
+                                                   sync=False)
             score = eager_maxsim if kind == "eager" else score_multi_vector_masked
             Psb = l2_normalize(param * pms.unsqueeze(-1))
             with torch.no_grad():
@@ -97,10 +101,11 @@ def main():
         for i in range(a.steps):
             last = step(i)
         torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / a.steps, last
+        return 1e3 * (time.perf_counter() - t0) / a.steps, (float(last.item()) if torch.is_tensor(last) else last)
 
     res = {}
-    kinds = ["call_pattern", "resident", "cached", "fused", "fused_cached", "fused_graph", "fused_cached_graph"] + (["eager"] if a.eager else [])
+    kinds = ["call_pattern", "resident", "cached", "fused", "fused_cached", "fused_nosync", "fused_cached_nosync", "fused_graph",
+             "fused_cached_graph"] + (["eager"] if a.eager else [])
     if a.only:
         kinds = [k for k in kinds if k in a.only.split(",")]
     for kind in kinds:

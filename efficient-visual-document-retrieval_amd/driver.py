@@ -444,12 +444,16 @@ class GraphedStep:
 
 
 def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStudent, temp: float,
-                         qidx: Optional[torch.Tensor] = None) -> float:
+                         qidx: Optional[torch.Tensor] = None, sync: bool = True):
+    """One fused update.  sync=True returns float(loss) like the reference's train_one_step (one host sync per step);
+    sync=False returns the loss as a device scalar and leaves the stream running, so that the host queues the next step
+    while this one executes (read the loss when it is logged)."""
     device = student.x.device
     Qb = Qb.to(device, non_blocking=True).float()
     qmb = qmb.to(device, non_blocking=True)
     qplanes = ops.split_f32(Qb)                                      # once per step, shared by teacher and student
-    return float(student.update(Qb, qmb, teacher.scores(Qb, qmb, qidx, qplanes=qplanes), temp, qplanes=qplanes).item())
+    loss = student.update(Qb, qmb, teacher.scores(Qb, qmb, qidx, qplanes=qplanes), temp, qplanes=qplanes)
+    return float(loss.item()) if sync else loss
 
 
 # ----------------------------------------------------------------------------------------------------

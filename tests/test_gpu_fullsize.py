@@ -247,6 +247,20 @@ def test_kernel_rate_floors(dev):
     ms1 = best_ms(lambda: corpus.score(Q[:1], None, out=out[:1]))
     tbs = 12000 * LP * D * 2 / ms1 / 1e9
     assert tbs > 3.5, f"single-query corpus streaming at {tbs:.2f} TB/s"
+    # the few-queries regime (two 4-wave workgroups per CU, 1 / 2 / 3 queries per wave): round 2 measured 1.57 / 2.27 / 2.78 ms
+    # at 40 k pages for 4 / 8 / 12 queries, i.e. 0.47 / 0.68 / 0.83 ms at 12 k pages
+    for nq_small, limit_ms in ((4, 0.80), (8, 1.10), (12, 1.35)):
+        msn = best_ms(lambda: corpus.score(Q[:nq_small], None, out=out[:nq_small]), reps=5)
+        assert msn < limit_ms, f"{nq_small} queries x 12000 pages took {msn:.3f} ms"
+    # ragged corpus (valid lengths 600-1030 + 4 masked in front): within ~5 % of the all-valid rate on valid patches
+    gm = torch.Generator(device=dev).manual_seed(23)
+    lens = torch.randint(600, LP + 1, (12000,), generator=gm, device=dev)
+    pm = torch.arange(LP, device=dev)[None, :] < lens[:, None]
+    pm[:, :4] = False
+    cr = PageCorpus.from_tensor(P, pm)
+    msr = best_ms(lambda: cr.score(Q, None, out=out))
+    tfr = 1024 * float(pm.sum()) * 2 * LQ * D / msr / 1e9
+    assert tfr > 1250, f"ragged + masked-prefix corpus at {tfr:.0f} TFLOP/s on valid patches"
     g = torch.Generator(device=dev).manual_seed(22)
     P32 = torch.nn.functional.normalize(torch.randn((2000, LP, D), generator=g, device=dev), dim=-1)
     Q32 = torch.nn.functional.normalize(torch.randn((512, LQ, D), generator=g, device=dev), dim=-1)
