@@ -296,9 +296,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
 // to one page -- 32 of the 33 tiles of such a page -- runs as ONE basic block: 2*ST half-tile steps x 2*QW chains per
 // wave with no branch, no scalar load and no wait other than the LDS counters in between, so the compiler overlaps
 // every epilogue and every ds_read with MFMAs of the following chains (the per-tile schedule lost ~28 % of the
-// matrix pipe to the gaps between tiles).  Other stages (tail tile, masked pages) take the per-tile path.
-// Tile masks of prefix-style pages (flag bit2) are derived from the valid length; mask words are only read for pages
-// with holes.
+// matrix pipe to the gaps between tiles).  A partial FIRST tile rides inside the same block (HEAD instance, bf16); in other
+// partially valid stages runs of full tiles go through a rolled per-tile loop and only partial tiles take the per-half path.
+// Tile masks of pages whose valid patches form one range (flag bit 2) are derived from the range, such pages are walked
+// only over the stages that hold a valid patch and only those tiles are fetched; mask words are read for pages with holes.
+// WAVES = 8: one workgroup per CU; WAVES = 4: two independent workgroups per CU (3-12 queries per launch).
+// NT: the corpus stream uses the non-temporal policy (launches in which every page is read by exactly one workgroup).
 //
 // NPL = 1: bf16 inputs, one product per k-step.
 // NPL = 2: fp32 inputs as two fp16 planes hi/lo of x * 2^k (k per tensor from its absmax, evdr_h2_shift): three plane
@@ -443,7 +446,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     }
 
     const uint32_t smem_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
-    // stage S = page (S / spp), tiles ST (S % spp) .. of that page (rows beyond the page are clamped: masked anyway)
+    // A stage = up to ST (+1) consecutive tiles of ONE page (rows beyond the page are clamped: masked anyway).
     // Per-lane byte offset of this lane's 16 B inside a 1-KiB piece: LDS row (4 piece + lane/16) of the tile receives source
     // chunk (lane%16) ^ (row & 15) of patch row (row0 + lane/16):
     // The DMA's lane offset is zero-extended, so rows past the page end (masked anyway) are clamped by clamping the
@@ -751,7 +754,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             if constexpr (DIAG) { const unsigned long long t = stamp(); d_ref += t - d_a; d_a = t; }
             const char* sbase = a_lane + slot * STAGE_BYTES;
             const int nt = (k == spp - 1) ? p.ntiles - t0 : ST;          // tiles in this stage (ST + 1 in an extended last stage)
-            // ---- generic path: one tile, per 16-patch half, masks from the valid length or the mask words
+            // ---- generic path: one tile, per 16-patch half, masks from the valid range or the mask words
             auto generic_tile = [&](int tis) {
                 const int tip = t0 + tis;
                 uint32_t tm;
@@ -905,7 +908,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                     // e.g. the text-prefix tokens in front of the image patches, utils/preprocess_data.py:101): runs of FULL
                     // tiles go through a rolled per-tile loop with the fast block's fragment prefetch and no mask logic in
                     // between (one tile = 32 x QW MFMAs per loop-back); only partial tiles take the per-half generic path, and
-                    // empty tiles cost nothing.  Which tiles are full: from the valid length, or from the mask words.
+                    // empty tiles cost nothing.  Which tiles are full: from the valid range, or from the mask words.
                     uint32_t fullbits = 0u;
                     if (va >= 0) {                                    // tiles [ceil(va/32), floor(vb/32)) of the page are full
                         int f0 = ((va + 31) >> 5) - t0, f1 = (vb >> 5) - t0;
