@@ -884,6 +884,9 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                                 for (int j = 0; j < QW; ++j)
 #pragma unroll
                                     for (int t = 0; t < 2; ++t) fold(acc[j][t], j, t, pb);
+                            // argmax on fp16 planes: the scheduler may not pull the next half-step's work above this half-step's
+                            // (VALU-heavy) fold -- it did, ran out of registers and spilled inside the block (23 -> 9 spilled VGPRs, -3.5 % time)
+                            if constexpr (NPL == 2 && ARGMAX) __builtin_amdgcn_sched_barrier(0);
                             }
                         }
                     };
@@ -977,6 +980,9 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                                     for (int j = 0; j < QW; ++j)
 #pragma unroll
                                         for (int t = 0; t < 2; ++t) fold(acc[j][t], j, t, pb);
+                                // argmax on fp16 planes: the scheduler may not pull the next half-step's work above this half-step's
+                                // (VALU-heavy) fold -- it did, ran out of registers and spilled inside the block (23 -> 9 spilled VGPRs, -3.5 % time)
+                                if constexpr (NPL == 2 && ARGMAX) __builtin_amdgcn_sched_barrier(0);
                                 }
                             }
                         }
@@ -1115,6 +1121,13 @@ extern "C" void evdr_experiment_set_dbg_buffer(void* dev_ptr) { g_dbg_buffer = (
 
 hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, int nplanes, bool want_argmax, int geom, hipStream_t stream) {
     const int ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
+#ifdef EVDR_EXPERIMENT
+    if (geom == 52 && nplanes == 2 && want_argmax && qw == 2) {      // stamped student-forward instance (scratch/diag_student.py)
+        EvdrFwdParams pd = p;
+        pd.dbg = evdr_experiment_dbg_buffer();
+        return launch16s<2, 2, true, 3, 2, true, true>(pd, stream);
+    }
+#endif
     if (nplanes == 2) {
         // 16-KiB tiles: 4-tile stages (2 x 5 x 16 KiB = all 160 KiB of LDS) or 3-tile stages, whichever sends fewer FULL tiles
         // through the per-tile path: a stage runs as the straight-line block only if all its tiles are full, and a lone
