@@ -44,7 +44,7 @@ def test_random_forward_all_kernels(seed):
     want = O.maxsim_masked(Q.float(), P.float(), qm, pm)
     args = (qm.to(dev), pm.to(dev))
     lib = L.load()
-    for variant in (0, 1, 2):                        # default, flat ring forced, staged without the priority schedule
+    for variant in (0, 1, 2, 30, 31):                # default, flat ring forced, no priority schedule, 8-wave workgroups only, no nt stream
         lib.evdr_debug_set_fwd_variant(variant)      # explicit test hook (include/evdr.h): the library reads no environment
         try:
             got, _ = ops.maxsim_forward(Q.to(dev), P.to(dev), *args)
