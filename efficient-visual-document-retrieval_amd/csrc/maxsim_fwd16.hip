@@ -836,6 +836,10 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                             // the same as chain()'s.
                             auto load_plane = [&](frag (&a)[4], int h, int pl) {
                                 const char* tb = sbase + (h >> 1) * TILE_B + (h & 1) * (16 * EVDR_D * 2) + pl * TILE_BYTES;
+                                // with the argmax the register file is full: the swizzle term is made opaque per call, so that the four
+                                // LDS address variants are rebuilt (4 VALU) instead of being hoisted out of the page loop and spilled
+                                int gx = g ^ c;
+                                if constexpr (ARGMAX || ST == 3) asm volatile("" : "+v"(gx));
 #pragma unroll
                                 for (int s4 = 0; s4 < 4; ++s4) a[s4] = *reinterpret_cast<const frag*>(tb + (((4 * s4) ^ gx) << 4));
                             };
@@ -940,6 +944,10 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                         } else {
                             auto load_plane = [&](frag (&a)[4], int h, int pl) {
                                 const char* tb = sbase + (h >> 1) * TILE_B + (h & 1) * (16 * EVDR_D * 2) + pl * TILE_BYTES;
+                                // with the argmax the register file is full: the swizzle term is made opaque per call, so that the four
+                                // LDS address variants are rebuilt (4 VALU) instead of being hoisted out of the page loop and spilled
+                                int gx = g ^ c;
+                                if constexpr (ARGMAX || ST == 3) asm volatile("" : "+v"(gx));
 #pragma unroll
                                 for (int s4 = 0; s4 < 4; ++s4) a[s4] = *reinterpret_cast<const frag*>(tb + (((4 * s4) ^ gx) << 4));
                             };
