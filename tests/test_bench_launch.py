@@ -54,3 +54,24 @@ def test_world_size_mismatch_and_missing_gpus_fail_loudly():
     if torch.cuda.device_count() < 8:
         r = subprocess.run([sys.executable, BENCH, "--gpus", "8"], capture_output=True, text=True, timeout=300, env=_clean_env())
         assert r.returncode == 2 and "visible GPUs" in r.stderr and r.stdout.strip() == ""
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The last committed bench line (profiles/r02_bench_n1.json, written by `python bench.py` on an MI355X) carries every field
+    the driver's contract names, the roofline object of the dominant kernel and the CPU baseline."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["higher_is_better"] is True and rec["vs_baseline"] is None and rec["data"] == "synthetic"
+    assert "workload" in rec["config"] and "model" not in rec["config"]
+    assert abs(rec["value"] - rec["config"]["pages"] * rec["config"]["queries_per_step"] / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
+    r = rec["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_flop_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    assert r["kernel"].startswith("maxsim_fwd16s_kernel<") and r["kernel_ms"] <= rec["ms_per_step"]
+    assert r["traffic"] is None or r["traffic_source"]["file"] == "profiles/hbm_traffic.json"
+    for o in r["other_regimes"]:
+        assert o["bound"] == "hbm" and o["peak"] == 8000.0 and 0.3 < o["frac"] < 1.0
+    c = rec["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["cores"] >= 1 and c["max_abs_diff_vs_gpu"] < 1e-4
