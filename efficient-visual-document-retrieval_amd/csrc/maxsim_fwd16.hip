@@ -311,8 +311,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
 // ARGMAX: also writes, per (query, page, token), the first patch index attaining the max (what torch.max returns and
 //          autograd routes the gradient to).
 // DIAG instantiation: s_memtime stamps around the segments of a wave's life, summed per wave and written to p.dbg
-// ([block][wave][8] cycles: total, prologue, barrier wait, top-of-stage refill, fast block, generic stage, page
-// finish, stages).  Its fences forbid overlaps the real kernel has: read SHARES, never its run time.
+// ([block][wave][8] cycles: total, prologue, barrier wait, top-of-stage refill, fast block, generic stage / tail tile,
+// page finish, control work in front of the barrier).  Its fences forbid overlaps the real kernel has: read SHARES, never its run time.
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     const bool ext = (p.ntiles % ST == 1) && (p.ntiles > ST);
     const int spp = ext ? p.ntiles / ST : (p.ntiles + ST - 1) / ST;      // stages per page
     const int nstages = npages * spp;
-    unsigned long long d_t0 = 0, d_pro = 0, d_bar = 0, d_ref = 0, d_fast = 0, d_gen = 0, d_fin = 0, d_a = 0;
+    unsigned long long d_t0 = 0, d_pro = 0, d_bar = 0, d_ref = 0, d_fast = 0, d_gen = 0, d_fin = 0, d_a = 0, d_ctl = 0, d_c0 = 0;
     if constexpr (DIAG) d_t0 = stamp();
 
     const int q0 = (qg * WAVES + wave) * QW;
@@ -646,6 +646,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     uint32_t pflags = 0u;
     int va = 0, vb = 0, first_masked = 0, khi = 0;
     while (npgi < npages) {
+        if constexpr (DIAG) d_c0 = stamp();
         // the compute cursor takes over the stage that was fetched last; the fetch cursor moves on
         const int pgi = npgi, k = nk;
         const int page = pg0 + pgi;
@@ -732,7 +733,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                     want |= (t >= ntlo && t <= nthi && t < p.ntiles) ? (1u << i) : 0u;
                 }
             }
-            if constexpr (DIAG) d_a = stamp();
+            if constexpr (DIAG) { d_a = stamp(); d_ctl += d_a - d_c0; }
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if constexpr (DIAG) { const unsigned long long t = stamp(); d_bar += t - d_a; d_a = t; }
@@ -910,6 +911,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                     if (spread) issue_extra(npgi, nk, p.ntiles, nslot);      // the next stage's tail-tile pieces, after the block
                     if constexpr (DIAG) { const unsigned long long t = stamp(); d_fast += t - d_a; d_a = t; }
                     if (nt > ST) generic_tile(ST);                       // tail tile riding in this (last) stage
+                    if constexpr (DIAG) { const unsigned long long t = stamp(); d_gen += t - d_a; d_a = t; }
                 } else {
                     // ---- partially valid stage (the boundary stage of a ragged page, a stage with a few masked patches --
                     // e.g. the text-prefix tokens in front of the image patches, utils/preprocess_data.py:101): runs of FULL
@@ -1072,7 +1074,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
         if (p.dbg != nullptr && lane == 0 && blockIdx.x < 4096) {
             unsigned long long* o = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
             o[0] = stamp() - d_t0; o[1] = d_pro; o[2] = d_bar; o[3] = d_ref; o[4] = d_fast; o[5] = d_gen; o[6] = d_fin;
-            o[7] = (unsigned long long)nstages;
+            o[7] = d_ctl;
         }
     }
 }

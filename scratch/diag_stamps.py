@@ -14,18 +14,9 @@ for _ in range(3): corpus.score(Q, None, out=out)
 torch.cuda.synchronize()
 d = dbg.cpu().double(); d = d[d[:, :, 0] > 0]            # waves that reported
 tot = d[:, 0]
-names = ["total", "prologue", "barrier wait", "refill at stage top", "fast block", "generic stage", "page finish"]
-print(f"waves reporting: {len(d)}, stages per block: {d[:,7].mean():.1f}, mean total cycles {tot.mean():.0f}")
+names = ["total", "prologue", "barrier wait", "refill at stage top", "fast block", "generic / tail tile", "page finish", "control before barrier"]
+NST = 61 * 4   # pages per workgroup x stages per page at 20 000 pages (informative only)
+print(f"waves reporting: {len(d)}, mean total cycles {tot.mean():.0f}")
 for i, n in enumerate(names[1:], 1):
-    print(f"{n:22s} {100*(d[:, i]/tot).mean():6.2f} %   ({d[:, i].mean()/d[:,7].mean():8.0f} cycles per stage)")
-print(f"{'unaccounted':22s} {100*(1 - (d[:,1:7].sum(1)/tot)).mean():6.2f} %")
-# fast block: 512 MFMA x 16 cycles = 8192 issue cycles per wave per full stage
-nfast = d[:, 7] * 4 / 5
-print(f"fast block cycles per full stage: {(d[:,4]/nfast).mean():.0f}  (MFMA issue floor for ONE wave 8192; two waves share a SIMD -> 16384)")
-
-raw = dbg.cpu().double()
-ok = raw[:, :, 0].min(dim=1).values > 0
-r = raw[ok]
-print("per wave slot: barrier wait / fast block cycles per stage")
-for w in range(8):
-    print(f"  wave {w}: barrier {r[:, w, 2].mean()/r[:, w, 7].mean():7.0f}   fast {r[:, w, 4].mean()/(r[:, w, 7].mean()*0.8):7.0f}")
+    print(f"{n:22s} {100*(d[:, i]/tot).mean():6.2f} %   ({d[:, i].mean()/NST:8.0f} cycles per stage)")
+print(f"{'unaccounted':22s} {100*(1 - (d[:,1:8].sum(1)/tot)).mean():6.2f} %")
