@@ -64,8 +64,9 @@ def main():
         graphed = student.graphed(B, Lq, 0.1, None if cached else teacher) if kind.endswith("_graph") else None
 
         def step(i):
-            idx = torch.arange(B) + (i % 64) * B
-            Qb, qmb = Qall[idx], qmall[idx]
+            idx = torch.arange(B) + (i % 64) * B                # host indices, as a DataLoader / the driver's permutation gives them
+            idx_dev = idx.to(dev, non_blocking=True)
+            Qb, qmb = Qall[idx_dev], qmall[idx_dev]
             if kind in ("resident", "cached"):
                 return driver.train_one_step(Qb, qmb, teacher, pmt, param, pms, opt, temp=0.1, qidx=idx if kind == "cached" else None)
             if kind == "fused_graph":                       # teacher forward + student update: one HIP-graph replay

@@ -30,6 +30,8 @@ SIGNATURES = {
     "evdr_maxsim_bwd_q": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     "evdr_maxsim_bwd_adamw": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                         _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp, _vp]),
+    "evdr_maxsim_bwd_adamw_planes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                               _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
     "evdr_adamw_advance": (C.c_int, [_vp, _f32, _f32, _vp]),
     "evdr_l2norm_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
     "evdr_l2norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
@@ -53,7 +55,7 @@ class EvdrError(RuntimeError):
         self.code = code
 
 
-ABI_VERSION = 300                  # EVDR_VERSION_NUM of csrc/evdr_common.h these signatures belong to
+ABI_VERSION = 301                  # EVDR_VERSION_NUM of csrc/evdr_common.h these signatures belong to
 
 _lib: Optional[C.CDLL] = None
 
@@ -92,5 +94,35 @@ def ptr(t) -> Optional[int]:
 
 
 def current_stream_handle(device) -> int:
+    """hipStream_t of torch's current stream on `device`, as an integer.  The raw getter (what torch's own compiled-code
+    launchers use) when this torch has it: torch.cuda.current_stream builds a Stream object per call, ~2 us of host time
+    in front of every launch."""
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+        return raw(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _Here:
+    """No-op context: the calling thread's current device already is the one the launch targets."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_HERE = _Here()
+
+
+def on(device):
+    """Context that makes `device` current for a launch: torch.cuda.device(device) only when it is not current already
+    (that guard costs ~3 us of host time per call, and a training step makes a dozen calls in front of a host sync)."""
+    import torch
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _HERE
+    return torch.cuda.device(device)

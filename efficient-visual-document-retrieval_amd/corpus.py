@@ -106,7 +106,7 @@ class PageCorpus:
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = ops.workspace(need, dev)       # allocated once per (corpus, batch size), not per search
         ws = self._ws
-        with torch.cuda.device(dev):
+        with L.on(dev):
             L.check(lib.evdr_maxsim_topk(
                 L.ptr(qp), L.ptr(self.planes), L.ptr(qm), L.ptr(self.tilemask), L.ptr(self.pageflags),
                 nq, lq, self.n_pages, self.lp, self.nplanes, self.p_stride, self.p_plane_stride,

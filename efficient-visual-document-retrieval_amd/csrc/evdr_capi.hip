@@ -252,17 +252,30 @@ int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, 
                           float* x, float* exp_avg, float* exp_avg_sq, int64_t nq, int64_t lq, int64_t np, int64_t lp,
                           int64_t d, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                           float l2_eps, const void* adamw_state_or_null, void* hip_stream) {
+    return evdr_maxsim_bwd_adamw_planes(g, Q, qmask, pmask, argmax, x, exp_avg, exp_avg_sq, nq, lq, np, lp, d, lr, beta1, beta2,
+                                        eps, weight_decay, step, l2_eps, adamw_state_or_null, nullptr, nullptr, nullptr,
+                                        hip_stream);
+}
+
+int evdr_maxsim_bwd_adamw_planes(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
+                                 const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq, int64_t nq, int64_t lq,
+                                 int64_t np, int64_t lp, int64_t d, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int64_t step, float l2_eps, const void* adamw_state_or_null,
+                                 void* next_planes_or_null, uint32_t* next_amax_or_null, uint32_t* pageflags_or_null,
+                                 void* hip_stream) {
     if (int rc = check_common(nq, lq, np, lp)) return rc;
     if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported", (long long)d);
     if (!adamw_state_or_null && step < 1) return fail(EVDR_ERR_ARG, "step must be >= 1 (1 for the first update)");
     if (np == 0 || lp == 0) return EVDR_OK;
     if (!x || !exp_avg || !exp_avg_sq) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_adamw: null parameter/state");
     if (nq > 0 && lq > 0 && (!g || !Q || !argmax)) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_adamw: null g/Q/argmax");
+    if (next_planes_or_null && !next_amax_or_null) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_adamw_planes: planes without their absmax word");
     const double bc1 = 1.0 - pow((double)beta1, (double)(step < 1 ? 1 : step));
     const double bc2 = 1.0 - pow((double)beta2, (double)(step < 1 ? 1 : step));
     hipError_t e = evdr_launch_maxsim_bwd_adamw(g, Q, qmask, pmask, argmax, x, exp_avg, exp_avg_sq, nq, lq, np, lp, lr, beta1,
                                                 beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), l2_eps,
-                                                adamw_state_or_null, (hipStream_t)hip_stream);
+                                                adamw_state_or_null, next_planes_or_null, next_amax_or_null,
+                                                pageflags_or_null, (hipStream_t)hip_stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd_adamw launch");
 }
 

@@ -29,6 +29,13 @@ struct AdamArgs {
     float* exp_avg_sq;   // second moment
     float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, eps_norm;
     const float* bc_dev; // null, or {bc1, bc2_sqrt} in device memory (step counted on the device: HIP-graph replays)
+    // null, or where the NEXT forward's operands go: l2_normalize(m * x_new) as the scorer's fp16 hi/lo planes (exactly what
+    // l2norm_fwd_kernel<true> would produce from the updated x), the absmax word of the planes and the page flag words that
+    // collect non-finite parameters -- the step's separate normalise pass (a read of x and a 20-us launch) disappears
+    _Float16* next_hi;
+    _Float16* next_lo;
+    uint32_t* next_amax;
+    uint32_t* pageflags;
 };
 
 // Device-resident step counter of an AdamW state: {int64 step; float bc1 = 1 - beta1^step; float bc2_sqrt}.  One thread; part
@@ -238,7 +245,38 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
             *reinterpret_cast<f32x4*>(ad.exp_avg + off + 4) = ea1;
             *reinterpret_cast<f32x4*>(ad.exp_avg_sq + off) = es0;
             *reinterpret_cast<f32x4*>(ad.exp_avg_sq + off + 4) = es1;
+            if (ad.next_hi != nullptr) {
+                // ---- the next step's l2_normalize(m * x): same expressions, same 16-lane reduction as l2norm_fwd_kernel
+                typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+                if (ad.pageflags != nullptr && m != 0.f) {
+                    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+                    const u32x4 b0 = __builtin_bit_cast(u32x4, x0), b1 = __builtin_bit_cast(u32x4, x1);
+                    bool bad = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) bad |= ((b0[k] & 0x7F800000u) == 0x7F800000u) || ((b1[k] & 0x7F800000u) == 0x7F800000u);
+                    if (bad) atomicOr(&ad.pageflags[page], 8u);
+                }
+                f32x4 y0 = x0 * m, y1 = x1 * m;
+                float s2 = y0[0] * y0[0] + y0[1] * y0[1] + y0[2] * y0[2] + y0[3] * y0[3] + y1[0] * y1[0] + y1[1] * y1[1] +
+                           y1[2] * y1[2] + y1[3] * y1[3];
+                for (int o = 8; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+                const float inv2 = 1.f / (sqrtf(s2) + ad.eps_norm);
+                y0 *= inv2;
+                y1 *= inv2;
+                constexpr int K = 141 - 127;              // evdr_h2_shift(bits of 1.0f): |y| <= 1
+                f16x8 a, b;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = __builtin_ldexpf((j < 4) ? y0[j & 3] : y1[j & 3], K);
+                    const _Float16 h = (_Float16)f;
+                    a[j] = h;
+                    b[j] = (_Float16)(f - (float)h);
+                }
+                *reinterpret_cast<f16x8*>(ad.next_hi + off) = a;
+                *reinterpret_cast<f16x8*>(ad.next_lo + off) = b;
+            }
         }
+        if (ad.next_amax != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *ad.next_amax = 0x3F800000u;
     }
     (void)lane;
 }
@@ -507,9 +545,10 @@ hipError_t evdr_launch_maxsim_bwd_adamw(const float* g, const float* Q, const ui
                                         const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq, int64_t nq,
                                         int64_t lq, int64_t np, int64_t lp, float lr, float beta1, float beta2, float eps,
                                         float weight_decay, float bc1, float bc2_sqrt, float eps_norm, const void* state,
-                                        hipStream_t stream) {
+                                        void* next_planes, uint32_t* next_amax, uint32_t* pageflags, hipStream_t stream) {
     AdamArgs ad{x, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, eps_norm,
-                state ? reinterpret_cast<const float*>(reinterpret_cast<const long long*>(state) + 1) : nullptr};
+                state ? reinterpret_cast<const float*>(reinterpret_cast<const long long*>(state) + 1) : nullptr,
+                (_Float16*)next_planes, next_planes ? (_Float16*)next_planes + np * lp * EVDR_D : nullptr, next_amax, pageflags};
     return dispatch_bwd<true>(g, Q, qmask, pmask, argmax, nullptr, nq, lq, np, lp, ad, stream);
 }
 

@@ -390,28 +390,36 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     bool active = qreal[0] >= 0;
     frag bq[QW][NPL][2][4];
     float qwt[QW][2];
+    // Query fragments come in THROUGH LDS (below, once the first stage is on its way): a fragment load straight from global
+    // memory touches 16 rows x 64 B per instruction -- half of every 128-B line -- and the four k-steps of a row are four
+    // instructions, each fetching its line from L2 again: 2 x the query bytes per workgroup, all 256 workgroups at once on
+    // the same 0.5 MB, and the load ISSUE of the prologue took 15.5 k cycles (stamped: 10 % of a 150 k-cycle student
+    // forward, 8 us of every launch).  Here: the mask bytes only.
+    int qrows[QW];                                        // wave-uniform: rows of query j that exist in Q (0 = no query)
+    bool qok[QW][2];
+    uint32_t qmk[QW][2];
+    // no mask: the same (unconditional) byte loads read query data and are ignored
+    const uint8_t* qmp = p.qmask != nullptr ? p.qmask : reinterpret_cast<const uint8_t*>(p.Q);
 #pragma unroll
     for (int j = 0; j < QW; ++j) {
         const int q = qreal[j];
+        // per_token: "query" q is the pack of single-token queries 32 q .. 32 q + 31, the last pack may be short
+        int nr = 0;
+        if (q >= 0) nr = p.per_token ? (int)min((int64_t)p.lq, p.per_token - (int64_t)q * 32) : p.lq;
+        qrows[j] = nr;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int tok = 16 * t + c;
-            // per_token: "query" q is the pack of single-token queries 32 q .. 32 q + 31, the last pack may be short
-            const bool ok = (q >= 0) && (tok < p.lq) && (!p.per_token || (int64_t)q * 32 + tok < p.per_token);
-            const int64_t row = (int64_t)q * p.q_stride + (int64_t)(p.tok0 + tok) * EVDR_D + g * 8;
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    frag v = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (ok) v = *reinterpret_cast<const frag*>(p.Q + pl * p.q_plane_stride + row + s * 32);
-                    bq[j][pl][t][s] = v;
-                }
-            float w = 0.f;
-            if (ok) w = (p.qmask == nullptr || p.qmask[(int64_t)q * p.lq_total + p.tok0 + tok] != 0) ? 1.f : 0.f;
-            qwt[j][t] = w;
+            const bool ok = 16 * t + c < nr;
+            qok[j][t] = ok;
+            qmk[j][t] = qmp[ok ? (int64_t)q * p.lq_total + p.tok0 + 16 * t + c : (int64_t)0];
         }
     }
+    auto set_qwt = [&]() {
+#pragma unroll
+        for (int j = 0; j < QW; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) qwt[j][t] = (qok[j][t] && (p.qmask == nullptr || qmk[j][t] != 0u)) ? 1.f : 0.f;
+    };
     uint32_t qbad[QW];                                    // wave-uniform: tokens of query j with a NaN / Inf element
     // fp16 planes carry x * 2^k: scores come back to real units with one exact power-of-two factor
     float inv = 1.f;
@@ -420,15 +428,9 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
         const int kp = p.p_amax ? evdr_h2_shift(*p.p_amax) : 0;
         inv = __builtin_ldexpf(1.f, -(kq + kp));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < QW; ++j) {                        // plane 0 is the hi plane: NaN and Inf survive the split there
-        uint32_t c0 = 0u, c1 = 0u;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { c0 |= frag_exp_carry(bq[j][0][0][s]); c1 |= frag_exp_carry(bq[j][0][1][s]); }
-        qbad[j] = token_bad_bits((c0 & 0x80008000u) != 0u, (c1 & 0x80008000u) != 0u);
-    }
     if (p.accumulate && p.argmax == nullptr) {          // later 32-token slice: see maxsim_fwd16_kernel
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        set_qwt();
         float any = 0.f;
 #pragma unroll
         for (int j = 0; j < QW; ++j) any += qwt[j][0] + qwt[j][1];
@@ -503,7 +505,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     // in-block refill: NPL pieces per tile of the straight-line block, one scalar base pointer per stage and one live VGPR.
     // Not in the QW = 2 argmax instance on fp16 planes, which is over the register budget as it is (it lost 7 us of 77 with
     // the refill in-block, rocprofv3 on the training step): that one refills at the top of the stage.
-    constexpr bool SPREAD = !(NPL == 2 && QW == 2 && ARGMAX);
+    constexpr bool SPREAD = true;
 
     typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
     cptr_t tilemask_c = (cptr_t)(uintptr_t)p.tilemask;
@@ -638,6 +640,59 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
         issue_stage(0, nk, tlo0, thi0, 0);
     }
     const uint16_t* fbase = stage_base(0, nk);
+    // ---- query fragments through LDS.  The first stage is on its way into slot 0; slot 1 is free until the refill that
+    // follows the first stage barrier.  One round per (query, plane): the wave's 32 token rows (8 KiB, the shape of a page
+    // tile) arrive in its own 8-KiB window of slot 1 as eight 1-KiB LDS-DMA pieces -- whole 128-B lines, each line fetched
+    // from L2 once -- with the page tiles' XOR swizzle, and leave it as MFMA fragments through the same ds_read_b128
+    // addressing as a page tile's.  Each wave reads back only what it fetched itself: vmcnt, no barrier.  Rows that do not
+    // exist (short queries, a short last token pack, no query at all) are clamped to an existing row and zeroed afterwards.
+    {
+        static_assert(WAVES * TILE_BYTES <= STAGE_BYTES, "the waves' query windows fit into ring slot 1");
+        const uint32_t qwin = STAGE_BYTES + wave * TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+            const int nr = max(qrows[j], 1);
+            const uint16_t* qb = p.Q + (int64_t)max(qreal[j], 0) * p.q_stride + (int64_t)p.tok0 * EVDR_D;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                if (j + pl > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the window's previous tenant has been read
+#pragma unroll
+                for (int piece = 0; piece < 8; ++piece) {
+                    const int row0 = piece * 4;
+                    const int rb = min(row0, nr - 1);
+                    uint32_t voff = voff0 ^ ((uint32_t)(piece & 3) << 6);
+                    if (row0 + 3 >= nr) voff = (voff & 0xFFu) + (uint32_t)(min(row0 + (lane >> 4), nr - 1) - rb) * 256u;
+                    lds_dma_16B_sbase(qb + (int64_t)pl * p.q_plane_stride + (int64_t)rb * EVDR_D, voff,
+                                      __builtin_amdgcn_readfirstlane(smem_base + qwin + piece * 1024));
+                }
+                wait_vmcnt<0>();
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        bq[j][pl][t][s4] = *reinterpret_cast<const frag*>(a_lane + qwin + t * (16 * EVDR_D * 2) + (((4 * s4) ^ gx) << 4));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    set_qwt();
+#pragma unroll
+    for (int j = 0; j < QW; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (!qok[j][t]) {
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bq[j][pl][t][s] = frag{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {                        // plane 0 is the hi plane: NaN and Inf survive the split there
+        uint32_t c0 = 0u, c1 = 0u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { c0 |= frag_exp_carry(bq[j][0][0][s]); c1 |= frag_exp_carry(bq[j][0][1][s]); }
+        qbad[j] = token_bad_bits((c0 & 0x80008000u) != 0u, (c1 & 0x80008000u) != 0u);
+    }
     if constexpr (DIAG) d_pro = stamp() - d_t0;
     const bool spread_ok = p.inblock_refill != 0;
     int slot = 0;
@@ -1136,6 +1191,11 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, i
         EvdrFwdParams pd = p;
         pd.dbg = evdr_experiment_dbg_buffer();
         return launch16s<2, 2, true, 3, 2, true, true>(pd, stream);
+    }
+    if (geom == 53 && nplanes == 2 && !want_argmax && qw == 2) {     // stamped teacher-forward instance (scratch/diag_teacher.py)
+        EvdrFwdParams pd = p;
+        pd.dbg = evdr_experiment_dbg_buffer();
+        return launch16s<2, 2, false, 4, 2, true, true>(pd, stream);
     }
 #endif
     if (nplanes == 2) {

@@ -138,6 +138,58 @@ __global__ void __launch_bounds__(256) split_h2_kernel(const float* __restrict__
     }
 }
 
+// Small tensors (a query batch: 32 x 32 x 128 fp32 = 512 KB): absmax and split in ONE launch.  Every workgroup reduces the
+// WHOLE tensor for itself (it sits in L2 after the first reader; 16 workgroups x 0.5 MB is nothing) and then splits its own
+// 8192 floats: no zeroing of the absmax word, no atomics, no second and third launch -- three launches in a row cost a
+// training step 15 us of mostly launch latency right in front of its first big kernel.
+__global__ void __launch_bounds__(1024) split_small_kernel(const float* __restrict__ x, int64_t n8, uint32_t* __restrict__ amax_bits,
+                                                           _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+    uint32_t m = 0;
+    const int64_t n4 = n8 * 2;
+    auto fold = [&](const f32x4& v) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float f = v[k];
+            const uint32_t b = __builtin_bit_cast(uint32_t, f) & 0x7FFFFFFFu;
+            if (b < 0x7F800000u) m = max(m, b);                  // non-finite elements do not set the scale (absmax_kernel)
+        }
+    };
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 1024 < n4; i += 8 * 1024) {                   // eight 16-B loads in flight per thread
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (i + u * 1024) * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fold(v[u]);
+    }
+    for (; i < n4; i += 1024) fold(*reinterpret_cast<const f32x4*>(x + i * 4));
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    __shared__ uint32_t wmax[16];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *amax_bits = m;
+    const int k = evdr_h2_shift(m);
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+    const int64_t e = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (e < n8) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + e * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + e * 8 + 4);
+        f16x8 a, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = __builtin_ldexpf((j < 4) ? v0[j & 3] : v1[j & 3], k);
+            const _Float16 h = (_Float16)f;
+            a[j] = h;
+            b[j] = (_Float16)(f - (float)h);
+        }
+        *reinterpret_cast<f16x8*>(hi + e * 8) = a;
+        *reinterpret_cast<f16x8*>(lo + e * 8) = b;
+    }
+}
+
 // Stable compaction of the queries that have a valid token in [tok0, tok0 + 32): one workgroup, 256 queries per round.
 __global__ void __launch_bounds__(256) build_qlist_kernel(const uint8_t* __restrict__ qmask, int nq, int lq, int tok0,
                                                          int32_t* __restrict__ qlist, int32_t* __restrict__ qcount) {
@@ -199,9 +251,14 @@ hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes,
 // the same for pages: non-finite elements of valid patches are reported in `pageflags` (bit 3) on the way
 hipError_t evdr_launch_split_f32_pages(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, const uint8_t* rowmask,
                                        int64_t rows_per_page, uint32_t* pageflags, hipStream_t stream) {
+    const int64_t n8 = rows * (EVDR_D / 8);
+    if (pageflags == nullptr && n8 > 0 && n8 <= 32768) {                 // <= 1 MB and nothing to report per page: one launch
+        hipLaunchKernelGGL(split_small_kernel, dim3((unsigned)((n8 + 1023) / 1024)), dim3(1024), 0, stream, x, n8, amax_bits,
+                           (_Float16*)planes, (_Float16*)planes + rows * EVDR_D);
+        return hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    const int64_t n8 = rows * (EVDR_D / 8);
     if (n8 == 0) return hipSuccess;
     int64_t blocks = (n8 + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;     // grid-stride beyond 8 blocks per CU

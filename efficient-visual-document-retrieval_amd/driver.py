@@ -287,12 +287,29 @@ def run(args) -> None:
             gen = torch.Generator().manual_seed(args.seed)
             perm, cursor = torch.randperm(n_train, generator=gen), 0
             t0, loss_sum, loss_cnt = time.time(), 0.0, 0
+            # fused single-process steps leave their loss on the device; the host reads the pending ones when a line is due
+            # (same numbers, same double-precision running sum in the same order: one sync per log line, not per step)
+            pending: list = []
+
+            def settle():
+                nonlocal loss_sum, loss_val
+                if pending:
+                    vals = torch.stack(pending).tolist()
+                    pending.clear()
+                    for v in vals:
+                        loss_sum += v
+                    loss_val = vals[-1]
+
+            defer = student is not None and world == 1 and tb is None
+            loss_val = 0.0
             for step in range(1, args.max_steps + 1):
                 if cursor >= n_train:                               # epoch boundary: reshuffle (DataLoader(shuffle=True))
                     perm, cursor = torch.randperm(n_train, generator=gen), 0
                 idx = perm[cursor:cursor + args.q_batch]
                 cursor += args.q_batch
                 qidx = idx if args.cache_teacher_scores else None
+                if Q_train.is_cuda:
+                    idx = idx.to(Q_train.device, non_blocking=True)      # one upload of the batch indices for both gathers
                 if world > 1 and student is not None:
                     loss_val = sharded_fused_train_one_step(Q_train[idx], qmask_train[idx], teacher, student, args.temp,
                                                            shard_sizes, qidx=qidx)
@@ -300,12 +317,19 @@ def run(args) -> None:
                     loss_val = sharded_train_one_step(Q_train[idx], qmask_train[idx], teacher, Pbar_param, pmask_s, opt,
                                                      args.temp, shard_sizes, qidx=qidx)
                 elif student is not None:
-                    loss_val = fused_train_one_step(Q_train[idx], qmask_train[idx], teacher, student, args.temp, qidx=qidx)
+                    loss_val = fused_train_one_step(Q_train[idx], qmask_train[idx], teacher, student, args.temp, qidx=qidx,
+                                                    sync=not defer)
                 else:
                     loss_val = train_one_step(Q_train[idx], qmask_train[idx], teacher, pmask_t, Pbar_param, pmask_s, opt,
                                               temp=args.temp, qidx=qidx)
-                loss_sum += loss_val
                 loss_cnt += 1
+                if defer:
+                    pending.append(loss_val)
+                    if (args.print_every and step % args.print_every == 0) or step % eval_every == 0 or step == args.max_steps \
+                            or len(pending) >= 256:
+                        settle()
+                else:
+                    loss_sum += loss_val
                 if tb is not None:
                     tb.add_scalar("train/loss", float(loss_val), step)
                 if args.print_every and step % args.print_every == 0:
@@ -358,14 +382,28 @@ class FusedStudent:
         self.steps = 0
         npg, ls, _ = self.x.shape
         self.tilemask, self.pageflags = ops.pack_pmask(self.pmask, npg, ls, self.x.device)     # the mask never changes
+        # l2_normalize(Pbar * pmask) as the scorer's planes: written by the update kernel for the NEXT step's forward; valid
+        # for the tensor object and version of x recorded in _planes_of (any torch in-place write to x invalidates them)
+        self._planes = None
+        self._planes_of = None
 
     def normalized(self) -> torch.Tensor:
         return ops.l2norm_forward(self.x, self.pmask, self.l2_eps)[0]
 
+    def planes(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(planes, absmax word) of l2_normalize(Pbar * pmask) for the current x: left behind by the last update, or made
+        here (first step, or x was written by something else since: a checkpoint restore, a manual edit)."""
+        if self._planes is not None and self._planes_of is not None and self._planes_of[0] is self.x \
+                and self._planes_of[1] == self.x._version:
+            return self._planes
+        self._planes = ops.l2norm_split(self.x, self.pmask, self.l2_eps, pageflags=self.pageflags, out=self._planes)  # a diverged page scores NaN
+        self._planes_of = (self.x, self.x._version)
+        return self._planes
+
     def scores(self, Qb, qmb, qplanes=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Student scores (B, n_pages) and the argmax the update needs.  l2_normalize(Pbar * pmask) lands directly in the
         scorer's fp16 hi/lo planes (no fp32 copy, no absmax/split pass).  `qplanes`: the batch's planes if already split."""
-        pplanes, pamax = ops.l2norm_split(self.x, self.pmask, self.l2_eps, pageflags=self.pageflags)   # a diverged page scores NaN
+        pplanes, pamax = self.planes()
         qplanes, qamax = qplanes if qplanes is not None else ops.split_f32(Qb)
         return ops.maxsim_forward_prepared(qplanes, qamax, pplanes, pamax, qmb, self.tilemask, self.pageflags,
                                            want_argmax=True)
@@ -375,8 +413,12 @@ class FusedStudent:
         self.steps += 1
         if state is not None:
             ops.adamw_advance(state, self.betas)
+        if self._planes is None:
+            self.planes()
         ops.maxsim_backward_adamw(dscore, Qb, qmb, self.pmask, arg, self.x, self.exp_avg, self.exp_avg_sq, self.lr,
-                                  self.betas, self.eps, self.weight_decay, self.steps, self.l2_eps, state=state)
+                                  self.betas, self.eps, self.weight_decay, self.steps, self.l2_eps, state=state,
+                                  next_planes=self._planes, pageflags=self.pageflags)
+        self._planes_of = (self.x, self.x._version)           # the kernel left the planes of the UPDATED x
 
     def update(self, Qb, qmb, sc_t, temp: float, state: Optional[torch.Tensor] = None, qplanes=None) -> torch.Tensor:
         """One step given the teacher scores; returns the loss as a device scalar (no host sync).  With `state` (a
@@ -426,6 +468,9 @@ class GraphedStep:
             self.loss = body()
         for t, k in zip((student.x, student.exp_avg, student.exp_avg_sq), keep):
             t.copy_(k)
+        # the captured step reads the planes its predecessor's update left behind: rebuild them for the restored x
+        student._planes_of = None
+        student.planes()
         student.steps = steps0
         self.state.zero_()
         if steps0:                                                   # resume: the device counter continues from steps0

@@ -50,7 +50,7 @@ def pack_pmask(pmask: Optional[torch.Tensor], npages: int, lp: int, dev) -> Tupl
     tilemask = torch.empty((npages, ntiles), dtype=torch.int32, device=dev)
     pageflags = torch.empty((npages,), dtype=torch.int32, device=dev)
     pm = _mask_u8(pmask, (npages, lp), dev)
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_pack_pmask(L.ptr(pm), npages, lp, L.ptr(tilemask), L.ptr(pageflags),
                                     L.current_stream_handle(dev)))
     return tilemask, pageflags
@@ -69,7 +69,7 @@ def flag_nonfinite(P: torch.Tensor, pmask: Optional[torch.Tensor], pageflags: to
         raise RuntimeError("flag_nonfinite needs (np, lp, 128) fp32 / bf16 / fp16 pages with dense rows")
     pm = _mask_u8(pmask, (npg, lp), dev)
     lib = L.load()
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_flag_nonfinite(L.ptr(P), kind, L.ptr(pm), npg, lp, int(P.stride(0)), L.ptr(pageflags),
                                         L.current_stream_handle(dev)))
 
@@ -86,7 +86,7 @@ def split_f32(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     rows = xc.numel() // D
     planes = torch.empty((2,) + tuple(xc.shape), dtype=torch.float16, device=dev)
     amax = torch.empty((1,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_split_f32(L.ptr(xc), rows, L.ptr(planes), L.ptr(amax), L.current_stream_handle(dev)))
     return planes, amax
 
@@ -124,7 +124,7 @@ def maxsim_forward(Q: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Tenso
     pm = _mask_u8(pmask, (npg, lp), dev)
     nbytes = lib.evdr_maxsim_fwd_workspace(nq, lq, npg, lp, dtype)
     ws = workspace(nbytes, dev)
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_maxsim_fwd(L.ptr(Qc), L.ptr(Pc), L.ptr(qm), L.ptr(pm), L.ptr(out), L.ptr(arg),
                                     nq, lq, npg, lp, d, dtype, strides, L.ptr(ws), ws.numel(),
                                     L.current_stream_handle(dev)))
@@ -155,7 +155,7 @@ def maxsim_forward_prepared(qplanes: torch.Tensor, qamax: Optional[torch.Tensor]
     qm = _mask_u8(qmask, (nq, lq), dev)
     qlist = torch.empty((nq + 1,), dtype=torch.int32, device=dev) if (lq > 32 and qm is not None and not want_argmax) else None
     lib = L.load()
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_maxsim_fwd_prepared(
             L.ptr(qplanes), L.ptr(pplanes), L.ptr(qm), L.ptr(tilemask), L.ptr(pageflags), view.data_ptr(), out.stride(0),
             L.ptr(arg), nq, lq, npg, lp, nplanes, int(pplanes.stride(1)), int(pplanes.stride(0)), L.ptr(qamax), L.ptr(pamax),
@@ -174,7 +174,7 @@ def maxsim_backward(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torch.Tens
     qm = _mask_u8(qmask, (nq, lq), dev)
     pm = _mask_u8(pmask, (npg, lp), dev)
     dP = torch.empty((npg, lp, d), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_maxsim_bwd(L.ptr(gc), L.ptr(Qc), L.ptr(qm), L.ptr(pm), L.ptr(argmax), L.ptr(dP),
                                     nq, lq, npg, lp, d, L.current_stream_handle(dev)))
     return dP
@@ -200,7 +200,7 @@ def topk(scores: torch.Tensor, k: int, idx_base: int = 0,
     row_stride = scores.stride(0) if nq > 1 else max(n, 1)
     wsb = lib.evdr_topk_workspace(nq, n, k)          # > 0: few long rows, ranked by many workgroups in two levels
     ws = workspace(wsb, dev) if wsb else None
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_topk(L.ptr(scores), L.ptr(im), nq, n, max(row_stride, n), idx_base, k, L.ptr(ts), L.ptr(ti),
                               L.ptr(ws), wsb, L.current_stream_handle(dev)))
     return ts, ti
@@ -241,7 +241,7 @@ def infonce_distill(score_s: torch.Tensor, score_t: torch.Tensor, temperature: f
     loss = torch.empty((), dtype=torch.float32, device=dev)
     row = torch.empty((b,), dtype=torch.float32, device=dev)
     grad = torch.empty_like(ss) if want_grad else None
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_infonce_distill_fwd_bwd(L.ptr(ss), L.ptr(st), b, n, float(temperature), L.ptr(loss),
                                                  L.ptr(grad), L.ptr(row), L.current_stream_handle(dev)))
     return loss, grad
@@ -258,14 +258,14 @@ def l2norm_forward(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float)
     y = torch.empty_like(xc)
     norm = torch.empty(xc.shape[:-1], dtype=torch.float32, device=dev)
     m = _mask_u8(rowmask, xc.shape[:-1], dev)
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_l2norm_fwd(L.ptr(xc), L.ptr(m), rows, D, float(eps), L.ptr(y), L.ptr(norm),
                                     L.current_stream_handle(dev)))
     return y, norm
 
 
 def l2norm_split(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float,
-                 pageflags: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                 pageflags: Optional[torch.Tensor] = None, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """y = m*x / (||m*x|| + eps) emitted directly as the scorer's fp16 hi/lo planes (see `split_f32`): ((2, ..., 128) fp16,
     absmax word).  One kernel instead of normalise -> absmax -> split, and no fp32 copy of y in HBM.  With `pageflags`
     (x is (np, lp, 128)) non-finite unmasked rows are reported in their page's flag word on the way (`flag_nonfinite`)."""
@@ -275,10 +275,15 @@ def l2norm_split(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float,
     lib = L.load()
     xc = x.contiguous()
     rows = xc.numel() // D
-    planes = torch.empty((2,) + tuple(xc.shape), dtype=torch.float16, device=dev)
-    amax = torch.empty((1,), dtype=torch.int32, device=dev)
+    if out is not None:                           # (planes, amax) of an earlier call, overwritten
+        planes, amax = out
+        if planes.shape != (2,) + tuple(xc.shape) or planes.dtype != torch.float16 or not planes.is_contiguous():
+            raise RuntimeError("l2norm_split: `out` planes do not match x")
+    else:
+        planes = torch.empty((2,) + tuple(xc.shape), dtype=torch.float16, device=dev)
+        amax = torch.empty((1,), dtype=torch.int32, device=dev)
     m = _mask_u8(rowmask, xc.shape[:-1], dev)
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_l2norm_fwd_split(L.ptr(xc), L.ptr(m), rows, D, float(eps), None, None, L.ptr(planes), L.ptr(amax),
                                           L.ptr(pageflags), int(xc.shape[-2]) if pageflags is not None else 1,
                                           L.current_stream_handle(dev)))
@@ -293,7 +298,7 @@ def l2norm_backward(gy: torch.Tensor, x: torch.Tensor, rowmask: Optional[torch.T
     rows = xc.numel() // D
     dx = torch.empty_like(xc)
     m = _mask_u8(rowmask, xc.shape[:-1], dev)
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_l2norm_bwd(L.ptr(gc), L.ptr(xc), L.ptr(m), L.ptr(norm), rows, D, float(eps), L.ptr(dx),
                                     L.current_stream_handle(dev)))
     return dx
@@ -302,10 +307,13 @@ def l2norm_backward(gy: torch.Tensor, x: torch.Tensor, rowmask: Optional[torch.T
 def maxsim_backward_adamw(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],
                           argmax: torch.Tensor, x: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
                           lr: float, betas: Tuple[float, float], eps: float, weight_decay: float, step: int,
-                          l2_eps: float = 1e-12, state: Optional[torch.Tensor] = None) -> None:
+                          l2_eps: float = 1e-12, state: Optional[torch.Tensor] = None, next_planes=None,
+                          pageflags: Optional[torch.Tensor] = None) -> None:
     """A6 + normalise/mask backward + AdamW in one launch, in place on x / exp_avg / exp_avg_sq (fp32, contiguous).
     `state` (see `adamw_state` / `adamw_advance`): bias corrections come from the device-side step counter instead of
-    `step` -- what a HIP-graph replay of the step needs."""
+    `step` -- what a HIP-graph replay of the step needs.  `next_planes` = (planes, amax) as `l2norm_split` returns them:
+    the launch also leaves l2_normalize(pmask * x_new) there for the next forward (and reports non-finite updated rows in
+    `pageflags`), so that the next step needs no normalise pass."""
     dev = _require_cuda(g, Q, argmax, x, exp_avg, exp_avg_sq)
     for t in (x, exp_avg, exp_avg_sq):
         if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != x.shape:
@@ -316,11 +324,16 @@ def maxsim_backward_adamw(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torc
     gc, Qc = g.float().contiguous(), Q.float().contiguous()
     qm = _mask_u8(qmask, (nq, lq), dev)
     pm = _mask_u8(pmask, (npg, lp), dev)
-    with torch.cuda.device(dev):
-        L.check(lib.evdr_maxsim_bwd_adamw(L.ptr(gc), L.ptr(Qc), L.ptr(qm), L.ptr(pm), L.ptr(argmax), L.ptr(x), L.ptr(exp_avg),
-                                          L.ptr(exp_avg_sq), nq, lq, npg, lp, d, float(lr), float(betas[0]), float(betas[1]),
-                                          float(eps), float(weight_decay), int(step), float(l2_eps), L.ptr(state),
-                                          L.current_stream_handle(dev)))
+    with L.on(dev):
+        planes, amax = next_planes if next_planes is not None else (None, None)
+        if planes is not None and (planes.shape != (2,) + tuple(x.shape) or planes.dtype != torch.float16 or not planes.is_contiguous()):
+            raise RuntimeError("maxsim_backward_adamw: `next_planes` do not match x")
+        L.check(lib.evdr_maxsim_bwd_adamw_planes(L.ptr(gc), L.ptr(Qc), L.ptr(qm), L.ptr(pm), L.ptr(argmax), L.ptr(x),
+                                                 L.ptr(exp_avg), L.ptr(exp_avg_sq), nq, lq, npg, lp, d, float(lr),
+                                                 float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
+                                                 float(l2_eps), L.ptr(state), L.ptr(planes), L.ptr(amax),
+                                                 L.ptr(pageflags) if planes is not None else None,
+                                                 L.current_stream_handle(dev)))
     for t in (x, exp_avg, exp_avg_sq):            # written through raw pointers: tell autograd (and version-keyed caches)
         torch.autograd.graph.increment_version(t)
 
@@ -334,7 +347,7 @@ def adamw_advance(state: torch.Tensor, betas: Tuple[float, float]) -> None:
     """step += 1 and refresh the bias corrections, on the device, on the current stream."""
     dev = _require_cuda(state)
     lib = L.load()
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_adamw_advance(L.ptr(state), float(betas[0]), float(betas[1]), L.current_stream_handle(dev)))
 
 
@@ -350,7 +363,7 @@ def maxsim_backward_q(g: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Te
     pm = _mask_u8(pmask, (npg, lp), dev)
     dQ = torch.empty((nq, lq, d), dtype=torch.float32, device=dev)
     ws = workspace(lib.evdr_maxsim_bwd_q_workspace(nq, lq, npg, lp), dev)
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(lib.evdr_maxsim_bwd_q(L.ptr(gc), L.ptr(Pc), L.ptr(qm), L.ptr(pm), L.ptr(argmax), L.ptr(dQ), nq, lq, npg, lp, d,
                                       L.ptr(ws), ws.numel(), L.current_stream_handle(dev)))
     return dQ

@@ -152,7 +152,19 @@ int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, 
                           int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d,
                           float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                           float l2_eps, const void* adamw_state_or_null, void* hip_stream);
-/* Device-resident step counter for the call above, so that a whole training step can be captured in a HIP graph and
+/* The same launch, also emitting the NEXT forward's operands: l2_normalize(m * x_new) of the updated parameter as the fp16
+ * hi/lo planes evdr_l2norm_fwd_split would produce from it (next_planes: 2 x np x lp x 128 fp16, next_amax: their absmax
+ * word; both or neither), non-finite updated rows reported in pageflags_or_null (np words, bit 3) like there.  A training
+ * loop that keeps the planes (mainv2_iter_distill_infonce.py:279 normalises the parameter at the top of EVERY step) saves
+ * the separate normalise pass: one read of x and one launch per step. */
+int evdr_maxsim_bwd_adamw_planes(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
+                                 const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq,
+                                 int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                 float l2_eps, const void* adamw_state_or_null,
+                                 void* next_planes_or_null, uint32_t* next_amax_or_null, uint32_t* pageflags_or_null,
+                                 void* hip_stream);
+/* Device-resident step counter for the calls above, so that a whole training step can be captured in a HIP graph and
  * replayed without a scalar from the host: adamw_state = 16 bytes of device memory {int64 step; float bc1; float bc2_sqrt},
  * zero-initialised.  evdr_adamw_advance does step += 1 and refreshes the bias corrections; evdr_maxsim_bwd_adamw with a
  * non-NULL state reads them from there and ignores its `step` argument. */

@@ -165,6 +165,44 @@ def test_fused_student_step_matches_golden_and_torch_adamw(golden):
     np.testing.assert_allclose(student.x.cpu().numpy(), param.detach().cpu().numpy(), atol=5e-6)
 
 
+def test_update_leaves_the_next_forwards_planes(golden):
+    """evdr_maxsim_bwd_adamw_planes: the planes the update kernel leaves for the next step are bit-for-bit what
+    evdr_l2norm_fwd_split makes of the updated parameter (so the step needs no normalise pass); a torch write to x
+    invalidates them; a parameter that went non-finite is flagged for the scorer like l2norm_split flags it."""
+    import evdr_amd  # noqa: F401
+    import golden_recipes as R
+    from evdr_amd import driver, ops
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    dev = torch.device("cuda:0")
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = R.train_case("b32n128")
+    pms = pms.clone()
+    pms[3, 17:] = False                                                # a ragged page and an empty one
+    pms[5] = False
+    teacher = driver.TeacherScorer(l2_normalize(Pt * pmt.unsqueeze(-1)).to(dev), pmt.to(dev))
+    student = driver.FusedStudent(Pbar0.to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+    for _ in range(3):
+        driver.fused_train_one_step(Qb, qmb, teacher, student, hp["temp"])
+        kept, kept_amax = student.planes()                             # left behind by the update: no launch here
+        assert student._planes_of[1] == student.x._version
+        fresh, fresh_amax = ops.l2norm_split(student.x, student.pmask, student.l2_eps)
+        assert torch.equal(kept.view(torch.int16), fresh.view(torch.int16))
+        assert int(kept_amax.item()) == int(fresh_amax.item())
+    # an external write: the kept planes are stale, planes() notices and rebuilds them
+    student.x.mul_(0.5)
+    student.x[7, 3] = 2.0
+    assert student._planes_of[1] != student.x._version
+    rebuilt, _ = student.planes()
+    fresh, _ = ops.l2norm_split(student.x, student.pmask, student.l2_eps)
+    assert torch.equal(rebuilt.view(torch.int16), fresh.view(torch.int16))
+    # a parameter that diverges inside the update is reported in the page flags (bit 3): the next scores of that page are NaN
+    student.exp_avg[9, 0, 0] = float("inf")
+    driver.fused_train_one_step(Qb, qmb, teacher, student, hp["temp"])
+    assert not torch.isfinite(student.x[9, 0, 0])
+    assert int(student.pageflags[9].item()) & 8 and not int(student.pageflags[8].item()) & 8
+    sc, _ = student.scores(Qb.to(dev).float(), qmb.to(dev))
+    assert torch.isnan(sc[:, 9]).all() and torch.isfinite(sc[:, 8]).all()
+
+
 @pytest.mark.parametrize("with_teacher", [True, False])
 def test_graphed_step_equals_eager_fused_step(golden, with_teacher):
     """FusedStudent.graphed: the step captured once in a HIP graph and replayed == the eager fused step, over several
