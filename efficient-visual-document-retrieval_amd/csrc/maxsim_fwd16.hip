@@ -502,10 +502,8 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
         for (int i = 0; i < G; ++i) issue_piece(sbp, k * ST, tlo, thi, slot, i, std::false_type{});
         issue_extra(pgi, k, thi, slot);
     };
-    // in-block refill: NPL pieces per tile of the straight-line block, one scalar base pointer per stage and one live VGPR.
-    // Not in the QW = 2 argmax instance on fp16 planes, which is over the register budget as it is (it lost 7 us of 77 with
-    // the refill in-block, rocprofv3 on the training step): that one refills at the top of the stage.
-    constexpr bool SPREAD = true;
+    // in-block refill: NPL pieces per tile of the straight-line block, one scalar base pointer per stage and one live VGPR
+    // (every instance: the QW = 2 argmax instance on fp16 planes, once excluded for its spills, has none left and gains 2 %)
 
     typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
     cptr_t tilemask_c = (cptr_t)(uintptr_t)p.tilemask;
@@ -772,7 +770,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             // (In-block, the whole next stage is fetched, also tiles outside the page's valid range.)
             const bool next_rows = (nk + 1) * ST * EVDR_TILE_PATCHES <= p.lp;     // every row of the next stage exists
             const bool next_full = refill && next_rows;
-            const bool spread = SPREAD && fast && next_full && spread_ok;
+            const bool spread = fast && next_full && spread_ok;
             // one base pointer for the whole next stage (two SGPRs), the tile window of its page, and which of this wave's G
             // pieces lie inside it
             const uint16_t* nbase = fbase;

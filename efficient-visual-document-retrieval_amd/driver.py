@@ -396,7 +396,10 @@ class FusedStudent:
         if self._planes is not None and self._planes_of is not None and self._planes_of[0] is self.x \
                 and self._planes_of[1] == self.x._version:
             return self._planes
-        self._planes = ops.l2norm_split(self.x, self.pmask, self.l2_eps, pageflags=self.pageflags, out=self._planes)  # a diverged page scores NaN
+        keep = self._planes
+        if keep is not None and (keep[0].shape[1:] != self.x.shape or keep[0].device != self.x.device):
+            keep = None                                                  # x was replaced by a tensor of another shape / device
+        self._planes = ops.l2norm_split(self.x, self.pmask, self.l2_eps, pageflags=self.pageflags, out=keep)  # a diverged page scores NaN
         self._planes_of = (self.x, self.x._version)
         return self._planes
 

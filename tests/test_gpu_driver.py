@@ -114,6 +114,21 @@ def test_driver_fused_step_flag(tmp_path):
         assert (out / "run" / "mf4" / "synth" / "best_ndcg5.npz").exists() or True
     assert len(logs["plain"]) == 12
     np.testing.assert_allclose(logs["fused"], logs["plain"], rtol=1e-4)
+    # the fused loop leaves the losses on the device and reads them when a line is due: with a line every 4 steps the logged
+    # values and the running average are the ones of the per-step run
+    out = tmp_path / "results_fused_batched"
+    driver.main(["--datasets", "synth", "--mapping_json", str(tmp_path / "map.json"), "--query_root", str(tmp_path),
+                 "--teacher_root", str(tmp_path), "--init_root", str(tmp_path), "--mfs", "4", "--out_root", str(out),
+                 "--name", "run", "--max_steps", "12", "--eval_every", "12", "--print_every", "4", "--q_batch", "32", "--fused_step"])
+    recs = {}
+    for tag, o in (("every", tmp_path / "results_fused"), ("batched", out)):
+        lines = (o / "run" / "mf4" / "synth" / "train.log").read_text().splitlines()
+        recs[tag] = {r["step"]: r for r in (json.loads(ln[ln.index("{"):]) for ln in lines if '"train/loss"' in ln)}
+    assert sorted(recs["batched"]) == [4, 8, 12]
+    for st in (4, 8, 12):
+        # (two runs of the step agree to fp32 noise, not to the bit: a heavy row's partial sums meet in LDS float atomics)
+        np.testing.assert_allclose(recs["batched"][st]["train/loss"], recs["every"][st]["train/loss"], rtol=1e-5)
+        np.testing.assert_allclose(recs["batched"][st]["train/avg_loss"], recs["every"][st]["train/avg_loss"], rtol=1e-5)
 
 
 def test_driver_step_matches_oracle():

@@ -315,6 +315,41 @@ def test_l2norm_split_planes(dev):
     assert torch.equal(arg, warg)
 
 
+@pytest.mark.parametrize("npg,lp,nq,lq", [(3, 1, 2, 5), (5, 37, 4, 32), (7, 128, 3, 17), (4, 206, 32, 32), (2, 300, 6, 32)])
+def test_update_kernel_emits_next_planes(dev, npg, lp, nq, lq):
+    """evdr_maxsim_bwd_adamw_planes over page lengths on both sides of the 128-row slab: the update equals the plain
+    evdr_maxsim_bwd_adamw one, and the planes it leaves are bit-for-bit evdr_l2norm_fwd_split of the updated parameter
+    (masked rows, an empty page, a zero row)."""
+    from evdr_amd import ops
+    gen = torch.Generator().manual_seed(1000 * lp + npg)
+    x0 = (torch.randn(npg, lp, 128, generator=gen) * 0.7).to(dev)
+    pm = (torch.rand(npg, lp, generator=gen) > 0.3)
+    pm[0] = True
+    if npg > 2:
+        pm[2] = False                                               # a page without a valid patch
+    pm = pm.to(dev)
+    x0 = x0 * pm.unsqueeze(-1)
+    Q = torch.nn.functional.normalize(torch.randn(nq, lq, 128, generator=gen), dim=-1).to(dev)
+    g = (torch.randn(nq, npg, generator=gen) * 1e-2).to(dev)
+    arg = torch.randint(0, lp, (nq, npg, lq), generator=gen).to(torch.int16).to(dev)
+    st = {}
+    for tag in ("plain", "planes"):
+        x, ea, es = x0.clone(), torch.zeros_like(x0), torch.zeros_like(x0)
+        tm, pf = ops.pack_pmask(pm, npg, lp, dev)
+        planes = ops.l2norm_split(x, pm, 1e-12, pageflags=pf) if tag == "planes" else None
+        for step in (1, 2):
+            ops.maxsim_backward_adamw(g, Q, None, pm, arg, x, ea, es, 1e-3, (0.9, 0.999), 1e-8, 1e-2, step, next_planes=planes,
+                                      pageflags=pf if planes is not None else None)
+        st[tag] = (x, ea, es, planes, pf)
+    for a, b in zip(st["plain"][:3], st["planes"][:3]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-7, rtol=1e-6)
+    x, _, _, (planes, amax), pf = st["planes"]
+    fresh, fresh_amax = ops.l2norm_split(x, pm, 1e-12)
+    assert torch.equal(planes.view(torch.int16), fresh.view(torch.int16)) and int(amax.item()) == int(fresh_amax.item()) == 0x3F800000
+    assert not (pf & 8).any()
+    assert float(x[~pm].abs().max() if (~pm).any() else 0.0) == 0.0   # masked rows never move
+
+
 @pytest.mark.parametrize("qs,ps", [(1.0, 1.0), (4096.0, 1.0 / 8192.0), (1e-3, 37.5), (250.0, 250.0)])
 def test_a1_fp32_path_any_magnitude(dev, ER, qs, ps):
     """fp32 inputs far from unit norm (the per-tensor power-of-two scaling of the fp16 planes): scores, argmax and the
