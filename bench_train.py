@@ -144,13 +144,16 @@ def main():
     t_kernel = kern()
     s_ms = timed(lambda: ops.maxsim_forward_prepared(qpl, qam, spl, sam, qmb, student.tilemask, student.pageflags, want_argmax=True))
     s_kernel = kern()
+    # as the step launches it: the update also leaves the next forward's fp16 hi/lo planes (evdr_maxsim_bwd_adamw_planes)
     u_ms = timed(lambda: ops.maxsim_backward_adamw(gscore, Qb, qmb, student.pmask, arg, student.x, student.exp_avg, student.exp_avg_sq,
-                                                   1e-3, (0.9, 0.999), 1e-8, 1e-2, 1, 1e-12))
+                                                   1e-3, (0.9, 0.999), 1e-8, 1e-2, 1, 1e-12, next_planes=(spl, sam),
+                                                   pageflags=student.pageflags))
     MFMA_F16_PEAK, HBM_PEAK = 2500.0, 8000.0          # TFLOP/s dense fp16/bf16, GB/s (MI355X_MICROARCH.md "Chip-level parameters")
     plane_products = 3                                 # lo*hi + hi*lo + hi*hi per fp32 product (csrc/maxsim_fwd16.hip)
     t_flop = 2.0 * B * N * Lq * Lt * D * plane_products
     s_flop = 2.0 * B * N * Lq * Ls * D * plane_products
-    u_bytes = N * Ls * D * 4 * 6 + B * N * Lq * 2 + B * N * 4       # x, exp_avg, exp_avg_sq read + written; argmax and g read
+    # x, exp_avg, exp_avg_sq read + written; the two fp16 planes written; argmax and g read
+    u_bytes = N * Ls * D * 4 * 6 + N * Ls * D * 2 * 2 + B * N * Lq * 2 + B * N * 4
     roof = [
         {"kernel": t_kernel, "role": "teacher forward (fp32 as fp16 hi/lo planes, 3 MFMA products)", "bound": "mfma", "kernel_ms": t_ms,
          "achieved": t_flop / t_ms / 1e9, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s", "frac": t_flop / t_ms / 1e9 / MFMA_F16_PEAK,
@@ -158,7 +161,7 @@ def main():
         {"kernel": s_kernel, "role": "student forward + argmax", "bound": "mfma", "kernel_ms": s_ms,
          "achieved": s_flop / s_ms / 1e9, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s", "frac": s_flop / s_ms / 1e9 / MFMA_F16_PEAK,
          "algorithmic_flop_per_launch": s_flop, "fp32_equivalent_tflops": s_flop / plane_products / s_ms / 1e9},
-        {"kernel": "maxsim_bwd_kernel<128,1024,true>", "role": "MaxSim backward gather + l2-normalise backward + AdamW, in place", "bound": "hbm",
+        {"kernel": "maxsim_bwd_kernel<128,1024,true>", "role": "MaxSim backward gather + l2-normalise backward + AdamW in place + next step's normalised fp16 planes", "bound": "hbm",
          "kernel_ms": u_ms, "achieved": u_bytes / u_ms / 1e6, "peak": HBM_PEAK, "unit": "GB/s", "frac": u_bytes / u_ms / 1e6 / HBM_PEAK,
          "algorithmic_bytes_per_launch": u_bytes},
     ]
