@@ -5,7 +5,8 @@ from evdr_amd.corpus import PageCorpus
 dev = torch.device("cuda:0"); pages = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
 P = B.gen_pages(0, pages, dev); corpus = PageCorpus.from_tensor(P, None)
 Qall, _ = B.make_queries(1024, pages, P, 0, pages, dev, 1)
-for nq in (1, 2, 4, 8, 12, 16, 24, 32, 40, 64, 128, 256, 1024):
+NQS = tuple(int(x) for x in sys.argv[2].split(',')) if len(sys.argv) > 2 else (1, 2, 4, 8, 12, 16, 24, 32, 40, 64, 128, 256, 1024)
+for nq in NQS:
     Q = Qall[:nq].contiguous(); out = torch.empty((nq, pages), dtype=torch.float32, device=dev)
     corpus.score(Q, None, out=out); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
