@@ -71,6 +71,21 @@ def test_committed_bench_line_follows_the_contract():
     assert abs(r["achieved"] - r["algorithmic_flop_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
     assert r["kernel"].startswith("maxsim_fwd16s_kernel<") and r["kernel_ms"] <= rec["ms_per_step"]
     assert r["traffic"] is None or r["traffic_source"]["file"] == "profiles/hbm_traffic.json"
+    if r["traffic"] is not None:
+        # the replayed counter figure is the committed file's (hash recorded in the line), taken for THIS kernel symbol and
+        # launch shape, and agrees with the rocprofv3 summary it was derived from
+        import hashlib
+        raw = open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "rb").read()
+        assert hashlib.sha256(raw).hexdigest().startswith(r["traffic_source"]["sha256"])
+        t = json.loads(raw)
+        assert t["kernel"] == r["kernel"] and t["queries"] == rec["config"]["queries_per_step"] and t["pages_per_gpu"] == rec["config"]["pages"]
+        assert r["traffic"] == t["hbm_bytes_per_launch"] >= r["algorithmic_bytes_per_launch"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        assert pmc["hbm_bytes_per_launch"] == t["hbm_bytes_per_launch"]
+    stats = open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv")).read().splitlines()
+    top = next(ln for ln in stats[1:] if "maxsim_fwd16s_kernel<4, 1, false, 8" in ln)
+    avg_ms = float(top.split('",')[1].split(",")[2]) / 1e6
+    assert abs(avg_ms - r["kernel_ms"]) < 0.01 * r["kernel_ms"]           # rocprofv3's average agrees with the HIP-event time of the line
     for o in r["other_regimes"]:
         assert o["bound"] == "hbm" and o["peak"] == 8000.0 and 0.3 < o["frac"] < 1.0
     c = rec["cpu_baseline"]
