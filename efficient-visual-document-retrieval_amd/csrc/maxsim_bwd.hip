@@ -203,11 +203,30 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
         f32x4* out = reinterpret_cast<f32x4*>(dP + ((int64_t)page * lp + r0) * EVDR_D);
         for (int i = tid; i < rows * (EVDR_D / 4); i += BW_THREADS) out[i] = reinterpret_cast<const f32x4*>(acc)[i];
     } else {
-        // one 16-lane group per parameter row: 8 floats per lane
-        for (int r = gid; r < rows; r += NGROUPS) {
+        // one 16-lane group per parameter row: 8 floats per lane.  The next row's parameter and moments are requested before
+        // this row's arithmetic and stores (two rows of loads in flight per group: the epilogue is a pure stream and each
+        // group has only four rows to hide its latency behind)
+        struct RowIn { f32x4 x0, x1, ea0, ea1, es0, es1; float m; };
+        auto load_row = [&](int r) {
+            RowIn in;
             const int64_t off = ((int64_t)page * lp + r0 + r) * EVDR_D + sub * 8;
-            const float m = (pmask == nullptr || pmask[(int64_t)page * lp + r0 + r] != 0) ? 1.f : 0.f;
-            f32x4 x0 = *reinterpret_cast<const f32x4*>(ad.x + off), x1 = *reinterpret_cast<const f32x4*>(ad.x + off + 4);
+            in.m = (pmask == nullptr || pmask[(int64_t)page * lp + r0 + r] != 0) ? 1.f : 0.f;
+            in.x0 = *reinterpret_cast<const f32x4*>(ad.x + off);
+            in.x1 = *reinterpret_cast<const f32x4*>(ad.x + off + 4);
+            in.ea0 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off);
+            in.ea1 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off + 4);
+            in.es0 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off);
+            in.es1 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off + 4);
+            return in;
+        };
+        RowIn nxt{};
+        if (gid < rows) nxt = load_row(gid);
+        for (int r = gid; r < rows; r += NGROUPS) {
+            const RowIn in = nxt;
+            if (r + NGROUPS < rows) nxt = load_row(r + NGROUPS);
+            const int64_t off = ((int64_t)page * lp + r0 + r) * EVDR_D + sub * 8;
+            const float m = in.m;
+            f32x4 x0 = in.x0, x1 = in.x1;
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(acc + r * EVDR_D + sub * 8);
             const f32x4 g1 = *reinterpret_cast<const f32x4*>(acc + r * EVDR_D + sub * 8 + 4);
             // ---- backward of y = (m x) / (||m x|| + eps_n)
@@ -222,8 +241,8 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
             const float c = (n > 0.f) ? dot * inv * inv / n : 0.f;
             const f32x4 d0 = (g0 * inv - v0 * c) * m, d1 = (g1 * inv - v1 * c) * m;
             // ---- AdamW (torch.optim.AdamW, amsgrad=False, maximize=False)
-            f32x4 ea0 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off), ea1 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off + 4);
-            f32x4 es0 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off), es1 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off + 4);
+            f32x4 ea0 = in.ea0, ea1 = in.ea1;
+            f32x4 es0 = in.es0, es1 = in.es1;
             const float decay = 1.f - ad.lr * ad.weight_decay;
             const float bc1 = ad.bc_dev ? ad.bc_dev[0] : ad.bc1;
             const float bc2_sqrt = ad.bc_dev ? ad.bc_dev[1] : ad.bc2_sqrt;
