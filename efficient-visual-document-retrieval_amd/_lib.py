@@ -43,6 +43,7 @@ SIGNATURES = {
     "evdr_maxsim_topk": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64, _vp, _vp, _i32, C.c_int,
                                    _vp, _vp, _vp, _sz, _vp]),
     "evdr_infonce_distill_fwd_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
+    "evdr_infonce_distill_fwd_bwd_ws": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
     "evdr_debug_set_fwd_variant": (C.c_int, [C.c_int]),
     "evdr_debug_set_pages_per_block": (C.c_int, [C.c_int]),
     "evdr_last_fwd_kernel": (C.c_char_p, []),

@@ -373,4 +373,15 @@ int evdr_infonce_distill_fwd_bwd(const float* score_s, const float* score_t, int
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "infonce launch");
 }
 
+int evdr_infonce_distill_fwd_bwd_ws(const float* score_s, const float* score_t, int64_t b, int64_t n, float temperature,
+                                    float* loss, float* dscore_or_null, void* workspace, void* hip_stream) {
+    if (b < 0 || n < 0) return fail(EVDR_ERR_ARG, "negative size");
+    if (!(temperature > 0.f)) return fail(EVDR_ERR_ARG, "temperature must be > 0");
+    if (b == 0 || n == 0) return fail(EVDR_ERR_SHAPE, "empty score matrix (b=%lld n=%lld)", (long long)b, (long long)n);
+    if (!score_s || !score_t || !loss || !workspace) return fail(EVDR_ERR_ARG, "evdr_infonce_distill_fwd_bwd_ws: null pointer");
+    hipError_t e = evdr_launch_infonce_ws(score_s, score_t, b, n, temperature, loss, dscore_or_null, (float*)workspace,
+                                          (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "infonce launch");
+}
+
 }  // extern "C"

@@ -136,3 +136,5 @@ hipError_t evdr_launch_topk(const float* scores, const int32_t* idx_map, int64_t
 int evdr_topk_segments(int64_t nq, int64_t n);
 hipError_t evdr_launch_infonce(const float* ss, const float* st, int64_t b, int64_t n, float temperature,
                                float* loss, float* dscore, float* row_loss, hipStream_t stream);
+hipError_t evdr_launch_infonce_ws(const float* ss, const float* st, int64_t b, int64_t n, float temperature, float* loss,
+                                  float* dscore, float* workspace, hipStream_t stream);

@@ -463,9 +463,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ticket != null: the workgroup that takes the last ticket also reduces the row losses (mean_kernel's order) -- one launch
+template <bool TICKET>
 __global__ void __launch_bounds__(256) infonce_row_kernel(const float* __restrict__ ss, const float* __restrict__ st,
                                                          int64_t n, float temp, float inv_tb,
-                                                         float* __restrict__ row_loss, float* __restrict__ dscore) {
+                                                         float* __restrict__ row_loss, float* __restrict__ dscore,
+                                                         unsigned int* __restrict__ ticket, float* __restrict__ loss) {
     __shared__ float red[4];
     __shared__ uint32_t redk[4];
     __shared__ int redi[4];
@@ -514,6 +517,29 @@ __global__ void __launch_bounds__(256) infonce_row_kernel(const float* __restric
         for (int64_t i = tid; i < n; i += 256) {
             const float pr = expf(s[i] / temp - smax) * inv_sum;
             d[i] = (pr - ((int)i == tidx ? 1.f : 0.f)) * inv_tb;
+        }
+    }
+    if constexpr (TICKET) {
+        __shared__ int is_last;
+        __syncthreads();                                   // tid 0's row_loss store is ordered before its fence below
+        if (tid == 0) {
+            __threadfence();
+            is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (is_last) {
+            __threadfence();
+            const volatile float* rl = row_loss;            // written by other CUs: read past this CU's vector L1
+            float v = 0.f;
+            for (int64_t i = tid; i < gridDim.x; i += 256) v += rl[i];
+            v = wave_sum(v);
+            __syncthreads();
+            if (lane == 0) red[wave] = v;
+            __syncthreads();
+            if (tid == 0) {
+                loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)gridDim.x;
+                *ticket = 0u;                               // ready for the next call
+            }
         }
     }
 }
@@ -638,11 +664,19 @@ hipError_t evdr_launch_l2norm_bwd(const float* gy, const float* x, const uint8_t
     return hipGetLastError();
 }
 
+hipError_t evdr_launch_infonce_ws(const float* ss, const float* st, int64_t b, int64_t n, float temperature, float* loss,
+                                  float* dscore, float* workspace, hipStream_t stream) {
+    if (b == 0) return hipSuccess;
+    hipLaunchKernelGGL(infonce_row_kernel<true>, dim3((unsigned)b), dim3(256), 0, stream, ss, st, n, temperature,
+                       1.f / (temperature * (float)b), workspace, dscore, reinterpret_cast<unsigned int*>(workspace + b), loss);
+    return hipGetLastError();
+}
+
 hipError_t evdr_launch_infonce(const float* ss, const float* st, int64_t b, int64_t n, float temperature, float* loss,
                                float* dscore, float* row_loss, hipStream_t stream) {
     if (b == 0) return hipSuccess;
-    hipLaunchKernelGGL(infonce_row_kernel, dim3((unsigned)b), dim3(256), 0, stream, ss, st, n, temperature,
-                       1.f / (temperature * (float)b), row_loss, dscore);
+    hipLaunchKernelGGL(infonce_row_kernel<false>, dim3((unsigned)b), dim3(256), 0, stream, ss, st, n, temperature,
+                       1.f / (temperature * (float)b), row_loss, dscore, (unsigned int*)nullptr, (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, row_loss, b, loss);

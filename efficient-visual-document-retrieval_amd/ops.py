@@ -228,6 +228,9 @@ def topk_with_ties(scores: torch.Tensor, k: int):
     return ts, ti, extra
 
 
+_INFONCE_WS: dict = {}
+
+
 def infonce_distill(score_s: torch.Tensor, score_t: torch.Tensor, temperature: float,
                     want_grad: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """A5 (criterion.py:56-68) + its closed-form gradient in one pass."""
@@ -239,11 +242,19 @@ def infonce_distill(score_s: torch.Tensor, score_t: torch.Tensor, temperature: f
     ss = score_s.float().contiguous()
     st = score_t.float().contiguous()
     loss = torch.empty((), dtype=torch.float32, device=dev)
-    row = torch.empty((b,), dtype=torch.float32, device=dev)
     grad = torch.empty_like(ss) if want_grad else None
+    stream = L.current_stream_handle(dev)
+    # per-row losses + the ticket word of the one-launch form: kept per (device, stream, batch), zeroed once -- the kernel
+    # leaves the ticket at zero, and calls on one stream run one after the other
+    key = (dev.index, stream, b)
+    ws = _INFONCE_WS.get(key)
+    if ws is None:
+        if len(_INFONCE_WS) > 64:
+            _INFONCE_WS.clear()
+        ws = _INFONCE_WS[key] = torch.zeros((b + 1,), dtype=torch.float32, device=dev)
     with L.on(dev):
-        L.check(lib.evdr_infonce_distill_fwd_bwd(L.ptr(ss), L.ptr(st), b, n, float(temperature), L.ptr(loss),
-                                                 L.ptr(grad), L.ptr(row), L.current_stream_handle(dev)))
+        L.check(lib.evdr_infonce_distill_fwd_bwd_ws(L.ptr(ss), L.ptr(st), b, n, float(temperature), L.ptr(loss),
+                                                    L.ptr(grad), L.ptr(ws), stream))
     return loss, grad
 
 

@@ -221,6 +221,14 @@ int evdr_infonce_distill_fwd_bwd(const float* score_s, const float* score_t, int
                                  float temperature, float* loss, float* dscore_or_null,
                                  float* row_loss, void* hip_stream);
 
+/* The same in ONE launch, for a caller that keeps a workspace across calls: `workspace` = (b + 1) 4-byte words of device
+ * memory, the last one a ticket counter that is ZERO before the first call and is left zero by every call (the last
+ * workgroup to finish reduces the per-row losses in a fixed order, so the loss is the same bits as above).  One workspace
+ * per stream that may run the call concurrently. */
+int evdr_infonce_distill_fwd_bwd_ws(const float* score_s, const float* score_t, int64_t b, int64_t n,
+                                    float temperature, float* loss, float* dscore_or_null,
+                                    void* workspace, void* hip_stream);
+
 /* ---- debug hooks: not part of the drop-in surface (tests and A/B measurements only) -----------------------------------
  * The library reads NO environment variable and takes no pointer from one; everything that changes its behaviour comes in
  * through a call.  evdr_debug_set_fwd_variant: force a forward-kernel family for the whole process (0 = default dispatch,
