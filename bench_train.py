@@ -55,6 +55,9 @@ def main():
     Qall = l2_normalize(torch.randn((64 * B, Lq, D), generator=g, device=dev))
     qmall = torch.ones((64 * B, Lq), dtype=torch.bool, device=dev)
 
+    order = torch.arange(64 * B)
+    order_dev = order.to(dev)
+
     def run(kind):
         param = torch.nn.Parameter(Pbar0.clone())
         opt = torch.optim.AdamW([param], lr=1e-3, weight_decay=1e-2)
@@ -64,9 +67,11 @@ def main():
         graphed = student.graphed(B, Lq, 0.1, None if cached else teacher) if kind.endswith("_graph") else None
 
         def step(i):
-            idx = torch.arange(B) + (i % 64) * B                # host indices, as a DataLoader / the driver's permutation gives them
-            idx_dev = idx.to(dev, non_blocking=True)
-            Qb, qmb = Qall[idx_dev], qmall[idx_dev]
+            # as in driver.py: the epoch's index order lives on the device (uploaded once per epoch), a batch's indices are a
+            # view of it; the host copy of the indices only keys the teacher-score cache
+            lo = (i % 64) * B
+            idx, idx_dev = order[lo:lo + B], order_dev[lo:lo + B]
+            Qb, qmb = Qall.index_select(0, idx_dev), qmall.index_select(0, idx_dev)
             if kind in ("resident", "cached"):
                 return driver.train_one_step(Qb, qmb, teacher, pmt, param, pms, opt, temp=0.1, qidx=idx if kind == "cached" else None)
             if kind == "fused_graph":                       # teacher forward + student update: one HIP-graph replay

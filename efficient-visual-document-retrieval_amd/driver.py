@@ -286,6 +286,9 @@ def run(args) -> None:
 
             gen = torch.Generator().manual_seed(args.seed)
             perm, cursor = torch.randperm(n_train, generator=gen), 0
+            # resident pseudo-queries: the epoch's permutation goes to the device once, a batch's indices are a view of it
+            # (no index upload per step) and the rows come out with index_select (half the host cost of advanced indexing)
+            perm_dev = perm.to(Q_train.device) if Q_train.is_cuda else None
             t0, loss_sum, loss_cnt = time.time(), 0.0, 0
             # fused single-process steps leave their loss on the device; the host reads the pending ones when a line is due
             # (same numbers, same double-precision running sum in the same order: one sync per log line, not per step)
@@ -305,22 +308,24 @@ def run(args) -> None:
             for step in range(1, args.max_steps + 1):
                 if cursor >= n_train:                               # epoch boundary: reshuffle (DataLoader(shuffle=True))
                     perm, cursor = torch.randperm(n_train, generator=gen), 0
+                    perm_dev = perm.to(Q_train.device) if Q_train.is_cuda else None
                 idx = perm[cursor:cursor + args.q_batch]
-                cursor += args.q_batch
                 qidx = idx if args.cache_teacher_scores else None
-                if Q_train.is_cuda:
-                    idx = idx.to(Q_train.device, non_blocking=True)      # one upload of the batch indices for both gathers
+                if perm_dev is not None:
+                    idx = perm_dev[cursor:cursor + args.q_batch]
+                cursor += args.q_batch
+                Qb_step, qmb_step = Q_train.index_select(0, idx), qmask_train.index_select(0, idx)
                 if world > 1 and student is not None:
-                    loss_val = sharded_fused_train_one_step(Q_train[idx], qmask_train[idx], teacher, student, args.temp,
+                    loss_val = sharded_fused_train_one_step(Qb_step, qmb_step, teacher, student, args.temp,
                                                            shard_sizes, qidx=qidx)
                 elif world > 1:
-                    loss_val = sharded_train_one_step(Q_train[idx], qmask_train[idx], teacher, Pbar_param, pmask_s, opt,
+                    loss_val = sharded_train_one_step(Qb_step, qmb_step, teacher, Pbar_param, pmask_s, opt,
                                                      args.temp, shard_sizes, qidx=qidx)
                 elif student is not None:
-                    loss_val = fused_train_one_step(Q_train[idx], qmask_train[idx], teacher, student, args.temp, qidx=qidx,
+                    loss_val = fused_train_one_step(Qb_step, qmb_step, teacher, student, args.temp, qidx=qidx,
                                                     sync=not defer)
                 else:
-                    loss_val = train_one_step(Q_train[idx], qmask_train[idx], teacher, pmask_t, Pbar_param, pmask_s, opt,
+                    loss_val = train_one_step(Qb_step, qmb_step, teacher, pmask_t, Pbar_param, pmask_s, opt,
                                               temp=args.temp, qidx=qidx)
                 loss_cnt += 1
                 if defer:
@@ -386,6 +391,8 @@ class FusedStudent:
         # for the tensor object and version of x recorded in _planes_of (any torch in-place write to x invalidates them)
         self._planes = None
         self._planes_of = None
+        self._loss_host = None          # pinned scalar + event of update(..., loss_to_host=True)
+        self._loss_event = None
 
     def normalized(self) -> torch.Tensor:
         return ops.l2norm_forward(self.x, self.pmask, self.l2_eps)[0]
@@ -423,13 +430,27 @@ class FusedStudent:
                                   next_planes=self._planes, pageflags=self.pageflags)
         self._planes_of = (self.x, self.x._version)           # the kernel left the planes of the UPDATED x
 
-    def update(self, Qb, qmb, sc_t, temp: float, state: Optional[torch.Tensor] = None, qplanes=None) -> torch.Tensor:
+    def update(self, Qb, qmb, sc_t, temp: float, state: Optional[torch.Tensor] = None, qplanes=None,
+               loss_to_host: bool = False) -> torch.Tensor:
         """One step given the teacher scores; returns the loss as a device scalar (no host sync).  With `state` (a
-        device-side step counter, ops.adamw_state) nothing in the step depends on a host scalar: graph-capturable."""
+        device-side step counter, ops.adamw_state) nothing in the step depends on a host scalar: graph-capturable.
+        `loss_to_host`: the loss is also copied to pinned host memory BEFORE the update kernel is launched
+        (`wait_loss()` returns it as soon as that copy has landed, while the update still runs)."""
         sc_s, arg = self.scores(Qb, qmb, qplanes)
         loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True)
+        if loss_to_host:
+            if self._loss_host is None:
+                self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
+                self._loss_event = torch.cuda.Event()
+            self._loss_host.copy_(loss, non_blocking=True)
+            self._loss_event.record()
         self.apply(dscore, Qb, qmb, arg, state)
         return loss
+
+    def wait_loss(self) -> float:
+        """The loss of the last update(..., loss_to_host=True): waits for its copy only, not for the update kernel behind it."""
+        self._loss_event.synchronize()
+        return float(self._loss_host.item())
 
     def graphed(self, batch: int, lq: int, temp: float, teacher: Optional["TeacherScorer"] = None) -> "GraphedStep":
         """The whole step captured ONCE in a HIP graph (torch.cuda.CUDAGraph): ~15 launches replayed with one call.
@@ -493,15 +514,18 @@ class GraphedStep:
 
 def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStudent, temp: float,
                          qidx: Optional[torch.Tensor] = None, sync: bool = True):
-    """One fused update.  sync=True returns float(loss) like the reference's train_one_step (one host sync per step);
+    """One fused update.  sync=True returns float(loss) like the reference's train_one_step (one host wait per step, for the
+    loss only: the parameter update may still be running when it returns -- later work on the stream is ordered behind it);
     sync=False returns the loss as a device scalar and leaves the stream running, so that the host queues the next step
     while this one executes (read the loss when it is logged)."""
     device = student.x.device
     Qb = Qb.to(device, non_blocking=True).float()
     qmb = qmb.to(device, non_blocking=True)
     qplanes = ops.split_f32(Qb)                                      # once per step, shared by teacher and student
-    loss = student.update(Qb, qmb, teacher.scores(Qb, qmb, qidx, qplanes=qplanes), temp, qplanes=qplanes)
-    return float(loss.item()) if sync else loss
+    loss = student.update(Qb, qmb, teacher.scores(Qb, qmb, qidx, qplanes=qplanes), temp, qplanes=qplanes, loss_to_host=sync)
+    # sync: the loss left for the host before the update kernel was launched, so float(loss) is back while that kernel (a
+    # seventh of the step) still runs and the caller's next launches queue up behind it instead of behind an idle GPU
+    return student.wait_loss() if sync else loss
 
 
 # ----------------------------------------------------------------------------------------------------
