@@ -197,7 +197,7 @@ def main():
                       "data": "synthetic", "vs_baseline": None,
                       "config": {"workload": "mainv2_iter_distill_infonce step (BASELINE.json configs[4])", "pages": N,
                                  "batch_queries": B, "teacher_patches": Lt, "student_patches": Ls, "steps": a.steps, "warmup": a.warmup},
-                      "modes": {"fused": "float(loss) returned every step, like the reference's train_one_step (one host sync per step)",
+                      "modes": {"fused": "float(loss) returned every step, like the reference's train_one_step (one host wait per step, for the loss only: it is copied out before the update kernel is launched)",
                                 "fused_nosync": "what driver.py's --fused_step loop does: losses stay on the device until a log line is due",
                                 "*_cached": "teacher scores from the per-query cache (frozen teacher)"},
                       "results": res, "roofline": roof, "cpu_baseline": cpu}))
