@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--pages", type=int, default=500)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=25)      # ~12 ms: past the clock ramp that follows a lighter mode
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--only", type=str, default="", help="comma list of modes to run (default: all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
