@@ -277,11 +277,12 @@ def test_split_f32_planes(dev):
     """evdr_split_f32: hi + lo == x * 2^k to 2^-21 relative, k from the absmax word, which holds the bits of max|x|."""
     from evdr_amd import ops
     gen = torch.Generator().manual_seed(78)
-    for scale in (1.0, 3e4, 2e-7):
-        x = (torch.randn(37, 19, 128, generator=gen) * scale).to(dev)
+    # 37 x 19 rows: the one-launch form for tensors up to 1 MB (a query batch); 300 x 32 rows: absmax pass + split pass
+    for scale, shape in ((1.0, (37, 19, 128)), (3e4, (37, 19, 128)), (2e-7, (37, 19, 128)), (1.0, (300, 32, 128)), (5e-3, (300, 32, 128))):
+        x = (torch.randn(*shape, generator=gen) * scale).to(dev)
         x[0, 0, :5] = 0.0
         planes, amax = ops.split_f32(x)
-        assert planes.shape == (2, 37, 19, 128) and planes.dtype == torch.float16
+        assert planes.shape == (2,) + shape and planes.dtype == torch.float16
         bits = int(amax.item())
         assert bits == int(x.abs().max().view(torch.int32).item())
         k = 141 - ((bits >> 23) & 0xFF)
