@@ -24,7 +24,7 @@ import torch
 from .. import ops
 from . import metrics as _metrics
 
-__all__ = ["get_torch_device", "BaseVisualRetrieverProcessor", "score_multi_vector_masked",
+__all__ = ["get_torch_device", "left_padding", "BaseVisualRetrieverProcessor", "score_multi_vector_masked",
            "CustomRetrievalEvaluator", "forget_prepared"]
 
 
@@ -144,6 +144,22 @@ def _left_pad_stack(seqs: List[torch.Tensor], device) -> torch.Tensor:
         if s.shape[0]:
             out[i, lmax - s.shape[0]:] = s if on_host else s.to(device)
     return out.to(device) if on_host else out
+
+
+def left_padding(sequences, batch_first=True, padding_value=0):
+    """Pad ragged (Li, D) sequences on the LEFT with `padding_value` to the longest one and stack them on the GPU:
+    (B, Lmax, D), or (Lmax, B, D) with batch_first=False; 1-D inputs count as one-token sequences
+    (evaluator/retrieval.py:30-45 -- the reference hard-codes device='cuda' there, so this helper needs a GPU too)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("left_padding places its result on the GPU like the reference (device='cuda'); no GPU is visible")
+    seqs = [s.unsqueeze(0) if s.ndim == 1 else s for s in sequences]
+    lmax = max(int(s.size(0)) for s in seqs)
+    d = int(seqs[0].size(-1))
+    out = torch.full((len(seqs), lmax, d), padding_value, dtype=seqs[0].dtype, device="cuda")
+    for i, s in enumerate(seqs):
+        if s.size(0):
+            out[i, lmax - s.size(0):] = s.to(device="cuda")
+    return out if batch_first else out.transpose(0, 1)
 
 
 class BaseVisualRetrieverProcessor(ABC):

@@ -163,7 +163,10 @@ def load_train_payload(train_npz: str):
     }
 
 
-load_test_payload = load_train_payload      # identical in the reference (preprocess_data.py:143-164)
+def load_test_payload(test_npz: str):
+    """Same keys as `load_train_payload` (the reference keeps two identical loaders, utils/preprocess_data.py:143-164);
+    the parameter carries the reference's name so that keyword calls keep working."""
+    return load_train_payload(test_npz)
 
 
 def load_init_payload(init_npz: str):

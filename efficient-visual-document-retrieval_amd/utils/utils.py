@@ -47,6 +47,18 @@ def log_json(logger, obj: Dict[str, Any]):
     logger.info(json.dumps(obj, ensure_ascii=False))
 
 
+def log_dict(logger, tb, scalars: Dict[str, Any], step: int):
+    """`{"step": step, **scalars}` as one JSON log line; the int / float entries also go to TensorBoard when a writer is
+    given (utils/utils.py:62-75 of the reference).  Returns the logger like the reference does."""
+    logger.info(json.dumps({"step": step, **scalars}, ensure_ascii=False))
+    if tb is not None:
+        for key, val in scalars.items():
+            if isinstance(val, (int, float)):
+                tb.add_scalar(key, val, step)
+        tb.flush()
+    return logger
+
+
 # ---- reproducibility / optimizer --------------------------------------------------------------------------------------
 def set_seed(seed: int):
     torch.manual_seed(seed)
