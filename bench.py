@@ -86,9 +86,10 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("EVDR_CPU_THREADS", "16"))))
 
 
-def cpu_baseline_leg(dev_corpus_slice: torch.Tensor, Qdev: torch.Tensor):
+def cpu_baseline_leg(dev_corpus_slice: torch.Tensor, Qdev: torch.Tensor, reps: int = 3):
     """The reference's scorer as restated in oracle/ (torch fp32 on the host, chunk_p=64), on a bounded slice of the
-    SAME workload: 32 queries x 4096 pages (about 10 s of host work).  A reported baseline, not a target."""
+    SAME workload: 32 queries x 2048 pages, median of `reps` passes (about 15 s of host work in all).  A
+    reported baseline, not a target."""
     from oracle import maxsim_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -97,23 +98,51 @@ def cpu_baseline_leg(dev_corpus_slice: torch.Tensor, Qdev: torch.Tensor):
     qm = torch.ones(Q.shape[:2], dtype=torch.bool)
     pm = torch.ones(P.shape[:2], dtype=torch.bool)
     O.maxsim_masked(Q[:4], P[:64], qm[:4], pm[:64], chunk_p=64)            # warm the thread pool
-    t0 = time.perf_counter()
-    s = O.maxsim_masked(Q, P, qm, pm, chunk_p=64)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        s = O.maxsim_masked(Q, P, qm, pm, chunk_p=64)
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
     pairs = Q.shape[0] * P.shape[0]
     return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{Q.shape[0]} queries x {P.shape[0]} pages of the same corpus, chunk_p=64, torch fp32 CPU, "
-                      f"{dt:.2f} s, {cores} threads"}, s
+            "sample": f"{Q.shape[0]} queries x {P.shape[0]} pages of the same corpus, chunk_p=64, torch fp32 CPU, median of "
+                      f"{reps} passes ({', '.join(f'{t:.2f}' for t in times)} s), {cores} threads"}, s
+
+
+def visible_gpu_count():
+    """GPUs on this host WITHOUT any HIP / HSA call (the launcher parent must stay GPU-free): KFD topology nodes that have
+    SIMDs, narrowed by the *_VISIBLE_DEVICES variables.  None when the KFD sysfs tree is not visible (then only the workers
+    can tell, and they do: see main)."""
+    import glob
+    import re
+    if not os.path.isdir("/sys/class/kfd/kfd/topology/nodes"):
+        return None
+    n = 0
+    for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            m = re.search(r"^simd_count\s+(\d+)", open(props).read(), re.M)
+        except OSError:
+            continue
+        if m and int(m.group(1)) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
 
 
 def self_launch(n: int, backend: str, need_gpus: bool = True) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this script, one per GPU, with the
-    rendezvous environment torch.distributed.run would give them, and wait.  This parent never touches the GPU (no HIP
-    call, no exec of a GPU-initialised process); rank 0's JSON line goes to the inherited stdout.  Returns the exit code."""
+    rendezvous environment torch.distributed.run would give them, and wait.  This parent never touches the GPU: devices are
+    counted from the KFD sysfs tree (`visible_gpu_count`), not through torch.cuda (which falls through to hipGetDeviceCount
+    when amdsmi is missing), and nothing is exec'ed from a GPU-initialised process; a worker that finds fewer GPUs than
+    ranks stops with the same message.  Rank 0's JSON line goes to the inherited stdout.  Returns the exit code."""
     import socket
     import subprocess
-    ndev = torch.cuda.device_count()                     # counts devices without initialising the runtime
-    if need_gpus and backend == "nccl" and ndev < n:
+    ndev = visible_gpu_count()
+    if need_gpus and backend == "nccl" and ndev is not None and ndev < n:
         print(f"bench.py: --gpus {n} with backend nccl needs {n} visible GPUs, found {ndev} "
               f"(--backend gloo rehearses N>1 on fewer GPUs)", file=sys.stderr)
         return 2
@@ -147,6 +176,46 @@ def self_launch(n: int, backend: str, need_gpus: bool = True) -> int:
     return rc
 
 
+def extras(dev, corpus_pages: torch.Tensor, args):
+    """The two other halves of the path, measured AFTER the timed retrieval region (N=1, rank 0; about 3 s in all) so that
+    the driver-run line carries them too:
+      train_step -- BASELINE.json configs[4] (mainv2_iter_distill_infonce.py:269-292) at B=32, N=500, Lt=1030, Ls=206: ms per step
+                    of the reference's call pattern, of the fused step and of the fused step with cached teacher scores, the
+                    kernel rooflines (executed AND algorithmic FLOP, named basis) and the oracle step on a bounded sample;
+      eval       -- BASELINE.json configs[1] through driver.eval_retrieval (mainv2_iter_distill_infonce.py:298-321): 500 planted
+                    queries x the first 500 pages of the corpus, end to end, split into device / copy / host-metric time, in
+                    bf16 (as configs[1] names it) and in fp32 (what the reference's scripts hand over)."""
+    import bench_train
+    from evdr_amd import driver
+    from evdr_amd.evaluator.retrieval import CustomRetrievalEvaluator
+    train = bench_train.measure(pages=500, batch=32, steps=30, warmup=15, kinds=["call_pattern", "fused", "fused_cached"],
+                                cpu_pages=125, cpu_reps=1, dev=dev)
+    n = min(500, corpus_pages.shape[0])
+    pages = corpus_pages[:n]
+    Qe, targets = make_queries(500, n, pages, 0, n, dev, 1)
+    docmap = {str(j): f"doc{j}" for j in range(n)}
+    qrels = {str(i): {docmap[str(int(t))]: 1} for i, t in enumerate(targets.tolist())}
+    pm = torch.ones(pages.shape[:2], dtype=torch.bool, device=dev)
+    qm = torch.ones(Qe.shape[:2], dtype=torch.bool, device=dev)
+    ev = CustomRetrievalEvaluator()
+    rec = {"config": {"workload": "driver.eval_retrieval, BASELINE.json configs[1] shape: 500 queries x 500 pages x 1030 patches, top-100, "
+                                  "metric tables at k = 1,3,5,10,50,70,100", "queries": 500, "pages": n},
+           "note": "median of 5 calls after 2 warm-ups; total_ms = the whole call incl. the page normalisation; device_ms = score + "
+                   "top-k by HIP events; d2h_ms = tie-rule candidate counts + the ONE device-to-host copy; host_ms = metric tables "
+                   "(numpy); nDCG under this repo's trec_eval-semantics metric (parity with mteb unpinned)"}
+    for name, (Qx, Px) in {"bf16": (Qe, pages), "fp32": (Qe.float(), pages.float())}.items():
+        runs = []
+        for i in range(7):
+            t = {}
+            m = driver.eval_retrieval(ev, Qx, qm, Px, pm, qrels, docmap, None, k=100, timing=t)
+            if i >= 2:
+                runs.append(t)
+        med = {k: sorted(r[k] for r in runs)[len(runs) // 2] for k in runs[0]}
+        rec[name] = {**med, "ndcg_at_5": m["NDCG"]["NDCG@5"], "recall_at_1": m["Recall"]["Recall@1"],
+                     "latency_ms_per_query": m["latency"]}
+    return train, rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +227,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-regimes", action="store_true",
                     help="skip the 1- and 8-query streaming launches (PMC passes aggregate over the launches they see)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `train_step` (configs[4]) and `eval` (configs[1]) records that follow the timed region at N=1")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse N>1 on a 1-GPU box)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -186,14 +257,42 @@ def main():
         else:
             print(json.dumps({"rendezvous": "ok", "world_size": 1, "ranks_seen": 1, "launcher": launcher}), flush=True)
         return
+    # EVDR_BENCH_ALLOW_SHARED_GPU=1: rehearsal hook -- lets several nccl ranks land on one GPU, which RCCL refuses; that refusal
+    # is how the gloo fallback below is exercised on a 1-GPU box
+    if world > 1 and args.backend == "nccl" and torch.cuda.device_count() < world and not os.environ.get("EVDR_BENCH_ALLOW_SHARED_GPU"):
+        print(f"bench.py: --gpus {world} with backend nccl needs {world} visible GPUs, found {torch.cuda.device_count()} "
+              f"(--backend gloo rehearses N>1 on fewer GPUs)", file=sys.stderr)
+        raise SystemExit(2)
     dev_index = local_rank % max(torch.cuda.device_count(), 1)     # gloo rehearsal: several ranks may share a GPU
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend, fallback_reason, ranks_seen = args.backend, None, 1
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        import datetime
+        if backend == "nccl":
+            # the first RCCL run with N > 1 happens on the driver's node, not in the build loop: if the communicator cannot
+            # be formed (an exception, on every rank alike), the exchange falls back to gloo through host memory -- 0.8 MB
+            # per rank and step -- and the line says so, instead of the run producing no record at all
+            try:
+                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                ranks_seen = int(probe.item())
+            except Exception as e:                       # noqa: BLE001
+                fallback_reason = f"{type(e).__name__}: {str(e)[:300]}"
+                try:
+                    dist.destroy_process_group()
+                except Exception:                        # noqa: BLE001
+                    pass
+                # a fresh store next door, hosted by rank 0 itself (under torchrun the first one lives in the agent)
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+                backend = "gloo"
+        if backend == "gloo":
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+            probe = torch.ones(1)
+            dist.all_reduce(probe)
+            ranks_seen = int(probe.item())
 
     import evdr_amd  # noqa: F401
     from evdr_amd.corpus import PageCorpus, ShardedRetriever, shard_range
@@ -211,7 +310,7 @@ def main():
         return retriever.search(Q, None, args.topk)
 
     def barrier():
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.barrier(device_ids=[dev_index])       # this rank's GPU, stated explicitly
         else:
             dist.barrier()
@@ -230,12 +329,60 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     pairs_per_step = args.queries * args.pages
     value = pairs_per_step / (ms_per_step * 1e-3)
+
+    # ---- where a step's time goes (instrumented passes AFTER the timed region; the timed steps above run unfenced): device
+    # phases by HIP events on the launch stream, the exchange by a host timer between a barrier and the arrival of the
+    # gathered candidates; per phase the mean over `reps` on this rank, then the max over ranks
+    from evdr_amd import ops as _ops
+    from evdr_amd.corpus import gather_candidates, merge_candidates
+
+    def phase_breakdown(reps=3):
+        acc = [0.0, 0.0, 0.0, 0.0]
+        sbuf = torch.empty((args.queries, corpus.n_pages), dtype=torch.float32, device=dev)
+        for _ in range(reps):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            e[0].record()
+            corpus.score(Q, None, out=sbuf)
+            e[1].record()
+            if corpus.n_pages:
+                ls, li = _ops.topk(sbuf, args.topk, idx_base=corpus.idx_base)
+            else:
+                ls, li = corpus.topk(Q, None, args.topk)
+            e[2].record()
+            torch.cuda.synchronize()
+            acc[0] += e[0].elapsed_time(e[1])
+            acc[1] += e[1].elapsed_time(e[2])
+            if world > 1:
+                barrier()
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+                sc, ix = gather_candidates(ls, li)
+                torch.cuda.synchronize()
+                acc[2] += (time.perf_counter() - th) * 1e3
+                e[3].record()
+                merge_candidates(sc, ix, args.topk)
+                e[4].record()
+                torch.cuda.synchronize()
+                acc[3] += e[3].elapsed_time(e[4])
+        mine = torch.tensor([a / reps for a in acc], dtype=torch.float64)
+        worst = mine.clone()
+        if world > 1:
+            w = worst.to(dev) if backend == "nccl" else worst
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            worst = w.cpu()
+        names = ("score_ms", "topk_ms", "exchange_ms", "merge_ms")
+        keep = 4 if world > 1 else 2
+        return {"rank0": {n: float(v) for n, v in zip(names[:keep], mine[:keep])},
+                "max_over_ranks": {n: float(v) for n, v in zip(names[:keep], worst[:keep])},
+                "note": "separate instrumented passes after the timed region (score and top-k as two calls; the timed step "
+                        "issues them through one C-ABI call), mean of %d" % reps}
+    phases = phase_breakdown()
 
     # ---- roofline of the dominant kernel: HIP events around the MaxSim launch on its own stream
     out = torch.empty((args.queries, corpus.n_pages), dtype=torch.float32, device=dev)
@@ -311,6 +458,9 @@ def main():
             cpu_base, s_cpu = cpu_baseline_leg(shard_pages[:n_cpu], Q)
             dmax = (out[:32, :n_cpu].cpu() - s_cpu).abs().max().item()      # same inputs: the oracle as checker
             cpu_base["max_abs_diff_vs_gpu"] = dmax
+        train_step = eval_rec = None
+        if world == 1 and not args.no_extras:
+            train_step, eval_rec = extras(dev, shard_pages, args)
         line = {
             "metric": "query-page pairs scored/sec", "value": value, "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -320,10 +470,14 @@ def main():
                        "pages": args.pages, "patches_per_page": LP, "dim": D, "queries_per_step": args.queries,
                        "query_tokens": LQ, "topk": args.topk, "parallelism": f"page-shard x{world}"},
             "queries_per_sec": args.queries / (ms_per_step * 1e-3), "ndcg_at_5": ndcg5,
-            "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
-                     "backend": dist.get_backend() if world > 1 else None, "launcher": launcher,
-                     "exchange": "all_gather_into_tensor of (nq, 2k) int32 per rank" if world > 1 else None},
+            "dist": {"world_size": dist.get_world_size() if world > 1 else 1, "ranks_seen": ranks_seen,
+                     "backend": dist.get_backend() if world > 1 else None, "backend_requested": args.backend if world > 1 else None,
+                     "backend_fallback_reason": fallback_reason, "launcher": launcher,
+                     "exchange": "all_gather_into_tensor of (nq, 2k) int32 per rank" if world > 1 else None,
+                     "pages_per_rank": corpus.n_pages},
+            "phases": phases,
             "roofline": roofline, "cpu_baseline": cpu_base,
+            "train_step": train_step, "eval": eval_rec,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

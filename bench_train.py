@@ -4,9 +4,13 @@ shape -- 32 queries x 32 tokens, N = 500 pages, teacher 1030 patches, student 20
 temperature 0.1, AdamW(lr 1e-3, wd 1e-2).  Reports ms/step of the drop-in functions used exactly like
 mainv2_iter_distill_infonce.py:269-292 ("call_pattern"), of the driver's resident-teacher step ("resident") and of
 the same with cached teacher scores ("cached"), of the fused student update ("fused", "fused_cached"; "_nosync": the loss
-stays on the device and the host queues the next step without waiting) and of its HIP-graph replay ("fused_graph",
-"fused_cached_graph"); `--eager` adds a plain torch restatement of the reference's four
-ATen ops on the same GPU for context.  Not the driver's headline bench (that is bench.py)."""
+stays on the device and the host queues the next step without waiting -- what driver.py --fused_step does between log
+lines) and of its HIP-graph replay ("fused_graph", "fused_cached_graph"); `--eager` adds a plain torch restatement of the
+reference's four ATen ops on the same GPU for context.
+
+`measure()` is also what bench.py calls for the `train_step` key of its JSON line (a short version: three modes, the
+kernel rooflines, the oracle step on a bounded sample), so that the driver-timed record carries the training half too.
+"""
 import argparse
 import json
 import os
@@ -16,6 +20,12 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+LT, LS, LQ, D = 1030, 206, 32, 128
+MFMA_F16_PEAK, MFMA_F32_PEAK, HBM_PEAK = 2500.0, 157.3, 8000.0    # TFLOP/s dense fp16/bf16, TFLOP/s fp32 MFMA, GB/s (MI355X_MICROARCH.md)
+PLANE_PRODUCTS = 3                                                 # lo*hi + hi*lo + hi*hi per fp32 product (csrc/maxsim_fwd16.hip)
+ALL_KINDS = ["call_pattern", "resident", "cached", "fused", "fused_cached", "fused_nosync", "fused_cached_nosync", "fused_graph",
+             "fused_cached_graph"]
 
 
 def eager_maxsim(Q, P, qmask, pmask, chunk_p=64):
@@ -30,98 +40,87 @@ def eager_maxsim(Q, P, qmask, pmask, chunk_p=64):
     return torch.cat(out, dim=1)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--pages", type=int, default=500)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=25)      # ~12 ms: past the clock ramp that follows a lighter mode
-    ap.add_argument("--eager", action="store_true")
-    ap.add_argument("--only", type=str, default="", help="comma list of modes to run (default: all)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
-    import evdr_amd  # noqa: F401
+def make_inputs(N: int, B: int, dev):
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    g = torch.Generator(device=dev).manual_seed(20261004)
+    Pt = l2_normalize(torch.randn((N, LT, D), generator=g, device=dev))
+    pmt = torch.ones((N, LT), dtype=torch.bool, device=dev)
+    pms = torch.ones((N, LS), dtype=torch.bool, device=dev)
+    Pbar0 = Pt[:, : LS * 5].reshape(N, LS, 5, D).mean(2) + 0.05 * torch.randn((N, LS, D), generator=g, device=dev)
+    Qall = l2_normalize(torch.randn((64 * B, LQ, D), generator=g, device=dev))
+    qmall = torch.ones((64 * B, LQ), dtype=torch.bool, device=dev)
+    return dict(N=N, B=B, dev=dev, Pt=Pt, pmt=pmt, pms=pms, Pbar0=Pbar0, Qall=Qall, qmall=qmall)
+
+
+def time_mode(inp, kind: str, steps: int, warmup: int):
+    """ms per step of one way of running the step (see the module docstring), and the last loss."""
     from evdr_amd import driver
     from evdr_amd.criterion import infonce_distillation_loss
     from evdr_amd.evaluator.retrieval import score_multi_vector_masked
     from evdr_amd.utils.preprocess_data import l2_normalize
-    dev = torch.device("cuda:0")
-    g = torch.Generator(device=dev).manual_seed(20261004)
-    N, B, Lt, Ls, Lq, D = a.pages, a.batch, 1030, 206, 32, 128
-    Pt = l2_normalize(torch.randn((N, Lt, D), generator=g, device=dev))
-    pmt = torch.ones((N, Lt), dtype=torch.bool, device=dev)
-    pms = torch.ones((N, Ls), dtype=torch.bool, device=dev)
-    Pbar0 = Pt[:, : Ls * 5].reshape(N, Ls, 5, D).mean(2) + 0.05 * torch.randn((N, Ls, D), generator=g, device=dev)
-    Qall = l2_normalize(torch.randn((64 * B, Lq, D), generator=g, device=dev))
-    qmall = torch.ones((64 * B, Lq), dtype=torch.bool, device=dev)
-
+    B, Pt, pmt, pms, Pbar0, Qall, qmall = inp["B"], inp["Pt"], inp["pmt"], inp["pms"], inp["Pbar0"], inp["Qall"], inp["qmall"]
     order = torch.arange(64 * B)
-    order_dev = order.to(dev)
+    order_dev = order.to(inp["dev"])
+    param = torch.nn.Parameter(Pbar0.clone())
+    opt = torch.optim.AdamW([param], lr=1e-3, weight_decay=1e-2)
+    cached = kind in ("cached", "fused_cached", "fused_cached_graph", "fused_cached_nosync")
+    teacher = driver.TeacherScorer(Pt, pmt, cache_size=Qall.shape[0] if cached else 0) if kind not in ("call_pattern", "eager") else None
+    student = driver.FusedStudent(Pbar0.clone(), pms, lr=1e-3, weight_decay=1e-2) if kind.startswith("fused") else None
+    graphed = student.graphed(B, LQ, 0.1, None if cached else teacher) if kind.endswith("_graph") else None
 
-    def run(kind):
-        param = torch.nn.Parameter(Pbar0.clone())
-        opt = torch.optim.AdamW([param], lr=1e-3, weight_decay=1e-2)
-        cached = kind in ("cached", "fused_cached", "fused_cached_graph", "fused_cached_nosync")
-        teacher = driver.TeacherScorer(Pt, pmt, cache_size=Qall.shape[0] if cached else 0) if kind not in ("call_pattern", "eager") else None
-        student = driver.FusedStudent(Pbar0.clone(), pms, lr=1e-3, weight_decay=1e-2) if kind.startswith("fused") else None
-        graphed = student.graphed(B, Lq, 0.1, None if cached else teacher) if kind.endswith("_graph") else None
+    def step(i):
+        # as in driver.py: the epoch's index order lives on the device (uploaded once per epoch), a batch's indices are a
+        # view of it; the host copy of the indices only keys the teacher-score cache
+        lo = (i % 64) * B
+        idx, idx_dev = order[lo:lo + B], order_dev[lo:lo + B]
+        Qb, qmb = Qall.index_select(0, idx_dev), qmall.index_select(0, idx_dev)
+        if kind in ("resident", "cached"):
+            return driver.train_one_step(Qb, qmb, teacher, pmt, param, pms, opt, temp=0.1, qidx=idx if kind == "cached" else None)
+        if kind == "fused_graph":                       # teacher forward + student update: one HIP-graph replay
+            return float(graphed(Qb, qmb).item())
+        if kind == "fused_cached_graph":                # teacher scores from the cache, student update replayed
+            return float(graphed(Qb, qmb, teacher.scores(Qb, qmb, idx)).item())
+        if kind in ("fused", "fused_cached"):
+            return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached" else None)
+        if kind in ("fused_nosync", "fused_cached_nosync"):     # loss stays on the device: no host sync inside the timed loop
+            return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached_nosync" else None,
+                                               sync=False)
+        score = eager_maxsim if kind == "eager" else score_multi_vector_masked
+        Psb = l2_normalize(param * pms.unsqueeze(-1))
+        with torch.no_grad():
+            sc_t = score(Qb, Pt, qmb, pmt, 64)
+        sc_s = score(Qb, Psb, qmb, pms, 64)
+        if kind == "eager":
+            loss = torch.nn.functional.cross_entropy(sc_s / 0.1, sc_t.argmax(dim=1))
+        else:
+            loss = infonce_distillation_loss(sc_s, sc_t, temperature=0.1)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return float(loss.item())
 
-        def step(i):
-            # as in driver.py: the epoch's index order lives on the device (uploaded once per epoch), a batch's indices are a
-            # view of it; the host copy of the indices only keys the teacher-score cache
-            lo = (i % 64) * B
-            idx, idx_dev = order[lo:lo + B], order_dev[lo:lo + B]
-            Qb, qmb = Qall.index_select(0, idx_dev), qmall.index_select(0, idx_dev)
-            if kind in ("resident", "cached"):
-                return driver.train_one_step(Qb, qmb, teacher, pmt, param, pms, opt, temp=0.1, qidx=idx if kind == "cached" else None)
-            if kind == "fused_graph":                       # teacher forward + student update: one HIP-graph replay
-                return float(graphed(Qb, qmb).item())
-            if kind == "fused_cached_graph":                # teacher scores from the cache, student update replayed
-                return float(graphed(Qb, qmb, teacher.scores(Qb, qmb, idx)).item())
-            if kind in ("fused", "fused_cached"):
-                return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached" else None)
-            if kind in ("fused_nosync", "fused_cached_nosync"):     # loss stays on the device: no host sync inside the timed loop
-                return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached_nosync" else None,
-                                                   sync=False)
-            score = eager_maxsim if kind == "eager" else score_multi_vector_masked
-            Psb = l2_normalize(param * pms.unsqueeze(-1))
-            with torch.no_grad():
-                sc_t = score(Qb, Pt, qmb, pmt, 64)
-            sc_s = score(Qb, Psb, qmb, pms, 64)
-            if kind == "eager":
-                loss = torch.nn.functional.cross_entropy(sc_s / 0.1, sc_t.argmax(dim=1))
-            else:
-                loss = infonce_distillation_loss(sc_s, sc_t, temperature=0.1)
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            opt.step()
-            return float(loss.item())
+    if cached:
+        for i in range(64):
+            step(i)                                   # fill the teacher-score cache (one epoch)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = step(i)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    return {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "last_loss": float(last.item()) if torch.is_tensor(last) else last}
 
-        if cached:
-            for i in range(64):
-                step(i)                                   # fill the teacher-score cache (one epoch)
-        for i in range(a.warmup):
-            step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            last = step(i)
-        torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / a.steps, (float(last.item()) if torch.is_tensor(last) else last)
 
-    res = {}
-    kinds = ["call_pattern", "resident", "cached", "fused", "fused_cached", "fused_nosync", "fused_cached_nosync", "fused_graph",
-             "fused_cached_graph"] + (["eager"] if a.eager else [])
-    if a.only:
-        kinds = [k for k in kinds if k in a.only.split(",")]
-    for kind in kinds:
-        ms, loss = run(kind)
-        res[kind] = {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "last_loss": loss}
-
-    # ---- roofline of each dominant kernel of the fused step: HIP events around the launch on torch's current stream (the
-    # stream the ctypes wrappers launch on), algorithmic work from the shapes
-    from evdr_amd import _lib as L, ops
-    Qb, qmb = Qall[:B].contiguous(), qmall[:B]
+def kernel_rooflines(inp, reps: int = 30):
+    """The three dominant kernels of the fused step, each timed with HIP events on torch's current stream (the stream the
+    ctypes wrappers launch on).  FLOP are stated twice: `algorithmic_flop_per_launch` is SURVEY §8(d)'s figure
+    (2 * B * N * Lq * Lp * D, what the reference's fp32 einsum computes) and `executed_flop_per_launch` is what the matrix
+    pipe really does for it (three fp16 plane products per fp32 product); `frac` is named by `frac_basis`."""
+    from evdr_amd import _lib as L, driver, ops
+    N, B, Pt, pmt, pms, Pbar0 = inp["N"], inp["B"], inp["Pt"], inp["pmt"], inp["pms"], inp["Pbar0"]
+    Qb, qmb = inp["Qall"][:B].contiguous(), inp["qmall"][:B]
     teacher = driver.TeacherScorer(Pt, pmt)
     student = driver.FusedStudent(Pbar0.clone(), pms, lr=1e-3, weight_decay=1e-2)
     sc_s, arg = student.scores(Qb, qmb)
@@ -129,7 +128,7 @@ def main():
     qpl, qam = ops.split_f32(Qb)
     spl, sam = ops.l2norm_split(student.x, student.pmask, 1e-12)
 
-    def timed(fn, reps=30):
+    def timed(fn):
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
@@ -153,54 +152,94 @@ def main():
     u_ms = timed(lambda: ops.maxsim_backward_adamw(gscore, Qb, qmb, student.pmask, arg, student.x, student.exp_avg, student.exp_avg_sq,
                                                    1e-3, (0.9, 0.999), 1e-8, 1e-2, 1, 1e-12, next_planes=(spl, sam),
                                                    pageflags=student.pageflags))
-    MFMA_F16_PEAK, HBM_PEAK = 2500.0, 8000.0          # TFLOP/s dense fp16/bf16, GB/s (MI355X_MICROARCH.md "Chip-level parameters")
-    plane_products = 3                                 # lo*hi + hi*lo + hi*hi per fp32 product (csrc/maxsim_fwd16.hip)
-    t_flop = 2.0 * B * N * Lq * Lt * D * plane_products
-    s_flop = 2.0 * B * N * Lq * Ls * D * plane_products
     # x, exp_avg, exp_avg_sq read + written; the two fp16 planes written; argmax and g read
-    u_bytes = N * Ls * D * 4 * 6 + N * Ls * D * 2 * 2 + B * N * Lq * 2 + B * N * 4
-    roof = [
-        {"kernel": t_kernel, "role": "teacher forward (fp32 as fp16 hi/lo planes, 3 MFMA products)", "bound": "mfma", "kernel_ms": t_ms,
-         "achieved": t_flop / t_ms / 1e9, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s", "frac": t_flop / t_ms / 1e9 / MFMA_F16_PEAK,
-         "algorithmic_flop_per_launch": t_flop, "fp32_equivalent_tflops": t_flop / plane_products / t_ms / 1e9},
-        {"kernel": s_kernel, "role": "student forward + argmax", "bound": "mfma", "kernel_ms": s_ms,
-         "achieved": s_flop / s_ms / 1e9, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s", "frac": s_flop / s_ms / 1e9 / MFMA_F16_PEAK,
-         "algorithmic_flop_per_launch": s_flop, "fp32_equivalent_tflops": s_flop / plane_products / s_ms / 1e9},
-        {"kernel": "maxsim_bwd_kernel<128,1024,true>", "role": "MaxSim backward gather + l2-normalise backward + AdamW in place + next step's normalised fp16 planes", "bound": "hbm",
-         "kernel_ms": u_ms, "achieved": u_bytes / u_ms / 1e6, "peak": HBM_PEAK, "unit": "GB/s", "frac": u_bytes / u_ms / 1e6 / HBM_PEAK,
+    u_bytes = N * LS * D * 4 * 6 + N * LS * D * 2 * 2 + B * N * LQ * 2 + B * N * 4
+
+    def mfma_entry(kernel, role, ms, lp):
+        alg = 2.0 * B * N * LQ * lp * D
+        exe = alg * PLANE_PRODUCTS
+        return {"kernel": kernel, "role": role, "bound": "mfma", "kernel_ms": ms,
+                "algorithmic_flop_per_launch": alg, "executed_flop_per_launch": exe,
+                "achieved": exe / ms / 1e9, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s", "frac": exe / ms / 1e9 / MFMA_F16_PEAK,
+                "frac_basis": "EXECUTED fp16-plane FLOP (3 MFMA products per fp32 product) / 2.5 PFLOP/s dense fp16 MFMA peak",
+                "algorithmic_tflops": alg / ms / 1e9, "frac_algorithmic_vs_fp16_peak": alg / ms / 1e9 / MFMA_F16_PEAK,
+                "algorithmic_vs_fp32_mfma_peak": alg / ms / 1e9 / MFMA_F32_PEAK}
+
+    return [
+        mfma_entry(t_kernel, "teacher forward (fp32 as fp16 hi/lo planes)", t_ms, LT),
+        mfma_entry(s_kernel, "student forward + argmax", s_ms, LS),
+        {"kernel": "maxsim_bwd_kernel<128,1024,true>",
+         "role": "MaxSim backward gather + l2-normalise backward + AdamW in place + next step's normalised fp16 planes",
+         "bound": "hbm", "kernel_ms": u_ms, "achieved": u_bytes / u_ms / 1e6, "peak": HBM_PEAK, "unit": "GB/s",
+         "frac": u_bytes / u_ms / 1e6 / HBM_PEAK, "frac_basis": "algorithmic bytes / 8 TB/s HBM3E spec",
          "algorithmic_bytes_per_launch": u_bytes},
     ]
 
-    # ---- CPU baseline: the oracle's restatement of the reference step (mainv2_iter_distill_infonce.py:269-292) on the host
-    # cores, same shapes (a reported baseline, not a target)
-    cpu = None
-    if not a.no_cpu_baseline:
-        import bench as HB
-        from oracle import maxsim_oracle as O
-        cores = HB.host_cores()
-        torch.set_num_threads(cores)
-        Qc, qmc, Ptc, pmtc, Pbc, pmsc = Qb.cpu(), qmb.cpu(), Pt.cpu(), pmt.cpu(), Pbar0.cpu(), pms.cpu()
-        O.distill_train_step(Qc[:4], qmc[:4], Ptc[:32], pmtc[:32], Pbc[:32], pmsc[:32], 0.1, 1e-3, 1e-2)      # warm the thread pool
-        t0 = time.perf_counter()
-        n_cpu = 2
-        for _ in range(n_cpu):
-            loss_c = O.distill_train_step(Qc, qmc, Ptc, pmtc, Pbc, pmsc, 0.1, 1e-3, 1e-2)[0]
-        dt = (time.perf_counter() - t0) / n_cpu
-        cpu = {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-               "sample": f"{n_cpu} full steps at the same shape (B={B}, N={N}, teacher {Lt}, student {Ls} patches), torch fp32 CPU, "
-                         f"{dt:.2f} s per step, {cores} threads", "loss": loss_c}
 
+def cpu_baseline(inp, n_pages: int, reps: int = 1):
+    """The oracle's restatement of the reference step (mainv2_iter_distill_infonce.py:269-292) on the host cores: full batch,
+    the first `n_pages` pages of the same teacher / student tensors (the step's cost is linear in the page count).  A
+    reported baseline, not a target."""
+    import bench as HB
+    from oracle import maxsim_oracle as O
+    B, N = inp["B"], inp["N"]
+    n_pages = min(n_pages, N)
+    cores = HB.host_cores()
+    torch.set_num_threads(cores)
+    Qc, qmc = inp["Qall"][:B].cpu(), inp["qmall"][:B].cpu()
+    Ptc, pmtc, Pbc, pmsc = inp["Pt"][:n_pages].cpu(), inp["pmt"][:n_pages].cpu(), inp["Pbar0"][:n_pages].cpu(), inp["pms"][:n_pages].cpu()
+    O.distill_train_step(Qc[:4], qmc[:4], Ptc[:32], pmtc[:32], Pbc[:32], pmsc[:32], 0.1, 1e-3, 1e-2)      # warm the thread pool
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        loss_c = O.distill_train_step(Qc, qmc, Ptc, pmtc, Pbc, pmsc, 0.1, 1e-3, 1e-2)[0]
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} step(s) of the oracle at B={B}, {n_pages} of the {N} pages (teacher {LT}, student {LS} patches), torch fp32 "
+                      f"CPU, {dt:.2f} s per step, {cores} threads",
+            "sample_pages": n_pages, "est_steps_per_sec_at_full_pages": (1.0 / dt) * n_pages / N, "loss": float(loss_c)}
+
+
+def measure(pages: int = 500, batch: int = 32, steps: int = 50, warmup: int = 25, kinds=None, cpu_pages: int = 500,
+            cpu_reps: int = 2, dev=None):
+    """The configs[4] record: modes -> ms/step, kernel rooflines, CPU baseline."""
+    dev = dev or torch.device("cuda:0")
+    inp = make_inputs(pages, batch, dev)
+    res = {kind: time_mode(inp, kind, steps, warmup) for kind in (kinds or ALL_KINDS)}
+    roof = kernel_rooflines(inp)
+    cpu = cpu_baseline(inp, cpu_pages, cpu_reps) if cpu_pages > 0 else None
+    return {"config": {"workload": "mainv2_iter_distill_infonce step (BASELINE.json configs[4])", "pages": pages,
+                       "batch_queries": batch, "teacher_patches": LT, "student_patches": LS, "steps": steps, "warmup": warmup},
+            "dtype": "f32 (fp16 hi/lo split MFMA)",
+            "modes": {"call_pattern": "the drop-in functions called exactly like the reference's train_one_step (autograd + torch AdamW)",
+                      "fused": "float(loss) returned every step, like the reference's train_one_step (one host wait per step, for the loss only: it is copied out before the update kernel is launched)",
+                      "fused_nosync": "what driver.py's --fused_step loop does between log lines: losses stay on the device until a line is due",
+                      "*_cached": "teacher scores from the per-query cache (frozen teacher)"},
+            "results": res, "roofline": roof, "cpu_baseline": cpu}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pages", type=int, default=500)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=25)      # ~12 ms: past the clock ramp that follows a lighter mode
+    ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--only", type=str, default="", help="comma list of modes to run (default: all)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    import evdr_amd  # noqa: F401
+    kinds = ALL_KINDS + (["eager"] if a.eager else [])
+    if a.only:
+        kinds = [k for k in kinds if k in a.only.split(",")]
+    rec = measure(a.pages, a.batch, a.steps, a.warmup, kinds, cpu_pages=0 if a.no_cpu_baseline else a.pages)
+    res = rec["results"]
     head = "fused" if "fused" in res else (kinds[0] if kinds else None)
     print(json.dumps({"metric": "InfoNCE-distillation steps/sec (mainv2_iter_distill_infonce.py train_one_step)",
                       "value": res[head]["steps_per_sec"] if head else None, "unit": "steps/s", "n_gpus": 1, "higher_is_better": True,
-                      "ms_per_step": res[head]["ms_per_step"] if head else None, "mode": head, "dtype": "f32 (fp16 hi/lo split MFMA)",
-                      "data": "synthetic", "vs_baseline": None,
-                      "config": {"workload": "mainv2_iter_distill_infonce step (BASELINE.json configs[4])", "pages": N,
-                                 "batch_queries": B, "teacher_patches": Lt, "student_patches": Ls, "steps": a.steps, "warmup": a.warmup},
-                      "modes": {"fused": "float(loss) returned every step, like the reference's train_one_step (one host wait per step, for the loss only: it is copied out before the update kernel is launched)",
-                                "fused_nosync": "what driver.py's --fused_step loop does: losses stay on the device until a log line is due",
-                                "*_cached": "teacher scores from the per-query cache (frozen teacher)"},
-                      "results": res, "roofline": roof, "cpu_baseline": cpu}))
+                      "ms_per_step": res[head]["ms_per_step"] if head else None, "mode": head, "data": "synthetic", "vs_baseline": None,
+                      **rec}))
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@ import torch.nn as nn
 from . import ops
 from .corpus import PageCorpus, shard_range
 from .criterion import infonce_distillation_loss
-from .evaluator.metrics import results_from_topk
+from .evaluator.metrics import EvalIndex, evaluate_topk, results_from_topk
 from .evaluator.retrieval import CustomRetrievalEvaluator, score_multi_vector_masked
 from .utils.preprocess_data import (_as_object_array, l2_normalize, load_init_payload, load_payload,
                                     load_query_payload, normalize_masked, preprocess_docs, preprocess_queries)
@@ -84,28 +84,72 @@ def train_one_step(Qb, qmb, teacher, pmask_teacher, Pbar_param, pmask_student, o
     return float(loss.item())
 
 
+_EVAL_INDEX: list = []          # [(relevant_docs, docidx_2_docid, qsidx_2_query, nq, n, k_values, EvalIndex)], newest last
+
+
+def eval_index(evaluator: CustomRetrievalEvaluator, relevant_docs, docidx_2_docid, qsidx_2_query, nq: int, n: int) -> EvalIndex:
+    """The lookup tables of one evaluation set (docid ranks for trec_eval's tie rule, judged pairs, ideal gains), built on
+    the first evaluation and reused while the SAME qrels / id-map objects come back (they are constant over a run: the
+    reference rebuilds its results dict from them on every evaluation, mainv2_iter_distill_infonce.py:311-317)."""
+    ks = tuple(evaluator.k_values)
+    for ent in _EVAL_INDEX:
+        if ent[0] is relevant_docs and ent[1] is docidx_2_docid and ent[2] is qsidx_2_query and ent[3:6] == (nq, n, ks):
+            return ent[6]
+    qkeys = [str(qsidx_2_query[i]) if qsidx_2_query is not None else str(i) for i in range(nq)]
+    docids = [docidx_2_docid[str(j)] for j in range(n)]
+    index = EvalIndex(relevant_docs, qkeys, docids, ks)
+    _EVAL_INDEX.append((relevant_docs, docidx_2_docid, qsidx_2_query, nq, n, ks, index))
+    del _EVAL_INDEX[:-4]
+    return index
+
+
 @torch.no_grad()
 def eval_retrieval(evaluator: CustomRetrievalEvaluator, Q_test_norm, qmask_test, Pbar_param, pmask_student,
                    relevant_docs_test, docidx_2_docid_test, qsidx_2_query_test, chunk_p: int = 64, k: int = 100,
-                   shard_sizes=None):
+                   shard_sizes=None, timing: Optional[Dict[str, float]] = None):
     """Retrieval metrics of the current student pages + "latency" (ms per query, synchronised).  With `shard_sizes`
     (page-sharded run) Pbar_param / pmask_student are this rank's pages and the score columns are all-gathered: every rank
-    ends up with the same full score matrix and the same metrics."""
+    ends up with the same full score matrix and the same metrics.
+
+    Scores, the top-k and the candidate counts of the tie rule stay on the device; ONE device-to-host copy brings
+    (nq, 2k + 1) words back and `evaluate_topk` turns them into the metric tables with array operations -- no per-pair
+    `.item()` (mainv2_iter_distill_infonce.py:311-317) and no per-query dict.  The numbers equal
+    `compute_mteb_metrics(relevant_docs, results_from_topk(...))` bit for bit (tests/test_host_logic.py).
+    `timing` (optional dict) receives the split of the call: device_ms (score + top-k, by HIP events), d2h_ms (candidate
+    counts of the tie rule + the one copy of the candidates), host_ms (index lookup + metric tables), total_ms (the whole
+    call, the normalisation of the pages included)."""
+    t_start = time.perf_counter()
+    kk = min(k, 128)
+    ev0, ev1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timing is not None else (None, None)
     P_now = l2_normalize(Pbar_param.detach() * pmask_student.unsqueeze(-1))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if ev0 is not None:
+        ev0.record()
     scores = score_multi_vector_masked(Q_test_norm, P_now, qmask_test, pmask_student, chunk_p=chunk_p)
     if shard_sizes is not None:
         scores = gather_columns(scores, tuple(shard_sizes))
-    ts, ti, tied = ops.topk_with_ties(scores, min(k, 128))     # ties cut at rank k: all tied candidates go to the metric
-    torch.cuda.synchronize()
-    latency_ms = (time.perf_counter() - t0) * 1000 / max(Q_test_norm.shape[0], 1)
+    if ev1 is None:
+        ts, ti, tied = ops.topk_with_ties(scores, kk, to_host=True)   # ties cut at rank k: all tied candidates go to the metric
+    else:                                                             # same work, with the device part fenced for the split
+        ts_d, ti_d = ops.topk(scores, kk)
+        ev1.record()
+        ev1.synchronize()
+        t_dev = time.perf_counter()
+        ts, ti, tied = ops.topk_with_ties(scores, kk, to_host=True, have=(ts_d, ti_d))
+    t1 = time.perf_counter()
+    latency_ms = (t1 - t0) * 1000 / max(Q_test_norm.shape[0], 1)
     nq, n = scores.shape
-    qkeys = [str(qsidx_2_query_test[i]) if qsidx_2_query_test is not None else str(i) for i in range(nq)]
-    docids = [docidx_2_docid_test[str(j)] for j in range(n)]
-    results = results_from_topk(ts.cpu().numpy(), ti.cpu().numpy(), qkeys, docids, extra=tied)
-    metrics = evaluator.compute_mteb_metrics(relevant_docs_test, results)
+    index = eval_index(evaluator, relevant_docs_test, docidx_2_docid_test, qsidx_2_query_test, nq, n)
+    if kk >= index.kmax or n <= kk:
+        metrics = evaluate_topk(index, ts, ti, tied)
+    else:                                                             # cut-offs beyond the device's top-k: the dict entry decides
+        metrics = evaluator.compute_mteb_metrics(relevant_docs_test, results_from_topk(ts, ti, index.query_keys, index.docids, extra=tied))
     metrics["latency"] = float(latency_ms)
+    if timing is not None:
+        t2 = time.perf_counter()
+        timing.update(device_ms=float(ev0.elapsed_time(ev1)), d2h_ms=(t1 - t_dev) * 1e3, host_ms=(t2 - t1) * 1e3,
+                      total_ms=(t2 - t_start) * 1e3)
     return metrics
 
 
@@ -297,13 +341,15 @@ def run(args) -> None:
             def settle():
                 nonlocal loss_sum, loss_val
                 if pending:
-                    vals = torch.stack(pending).tolist()
-                    pending.clear()
-                    for v in vals:
+                    vals = torch.stack([l for _, l in pending]).tolist()
+                    for (s_no, _), v in zip(pending, vals):
                         loss_sum += v
+                        if tb is not None:                           # the TensorBoard scalars are buffered with the losses
+                            tb.add_scalar("train/loss", float(v), s_no)
+                    pending.clear()
                     loss_val = vals[-1]
 
-            defer = student is not None and world == 1 and tb is None
+            defer = student is not None and world == 1              # with or without TensorBoard: no host wait per step
             loss_val = 0.0
             for step in range(1, args.max_steps + 1):
                 if cursor >= n_train:                               # epoch boundary: reshuffle (DataLoader(shuffle=True))
@@ -329,13 +375,13 @@ def run(args) -> None:
                                               temp=args.temp, qidx=qidx)
                 loss_cnt += 1
                 if defer:
-                    pending.append(loss_val)
+                    pending.append((step, loss_val))
                     if (args.print_every and step % args.print_every == 0) or step % eval_every == 0 or step == args.max_steps \
                             or len(pending) >= 256:
                         settle()
                 else:
                     loss_sum += loss_val
-                if tb is not None:
+                if tb is not None and not defer:
                     tb.add_scalar("train/loss", float(loss_val), step)
                 if args.print_every and step % args.print_every == 0:
                     log_json(logger, {"dataset": dataset, "mf": mf, "step": step, "train/loss": float(loss_val),
@@ -393,6 +439,17 @@ class FusedStudent:
         self._planes_of = None
         self._loss_host = None          # pinned scalar + event of update(..., loss_to_host=True)
         self._loss_event = None
+        self._loss_ws: Dict[int, torch.Tensor] = {}     # batch size -> workspace of the one-launch loss, owned by this student
+
+    def loss_workspace(self, b: int) -> torch.Tensor:
+        """Per-row losses + ticket word of the one-launch InfoNCE kernel for batches of `b` queries, zeroed when first asked
+        for (never inside a stream capture: GraphedStep asks before it captures).  Owned by this student and kept for its
+        lifetime, so a captured graph's baked pointer stays valid; steps of one student are ordered by their updates of x, so
+        the workspace is never used by two launches at once."""
+        ws = self._loss_ws.get(int(b))
+        if ws is None or ws.device != self.x.device:
+            ws = self._loss_ws[int(b)] = ops.infonce_workspace(b, self.x.device)
+        return ws
 
     def normalized(self) -> torch.Tensor:
         return ops.l2norm_forward(self.x, self.pmask, self.l2_eps)[0]
@@ -437,7 +494,7 @@ class FusedStudent:
         `loss_to_host`: the loss is also copied to pinned host memory BEFORE the update kernel is launched
         (`wait_loss()` returns it as soon as that copy has landed, while the update still runs)."""
         sc_s, arg = self.scores(Qb, qmb, qplanes)
-        loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True)
+        loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True, ws=self.loss_workspace(sc_s.shape[0]))
         if loss_to_host:
             if self._loss_host is None:
                 self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
@@ -472,6 +529,7 @@ class GraphedStep:
         self.qmb = torch.ones((batch, lq), dtype=torch.bool, device=dev)
         self.sc_t = torch.zeros((batch, n), dtype=torch.float32, device=dev)
         self.state = ops.adamw_state(dev)
+        student.loss_workspace(batch)                                # zeroed NOW, outside the capture below
 
         def body():
             qplanes = ops.split_f32(self.Qb)                         # once per step, shared by teacher and student
@@ -583,7 +641,7 @@ def sharded_fused_train_one_step(Qb, qmb, teacher_shard: "TeacherScorer", studen
     sc_s_local, arg = student_shard.scores(Qb, qmb, qplanes)
     sc_t = gather_columns(teacher_shard.scores(Qb, qmb, qidx, qplanes=qplanes), tuple(shard_sizes), group)
     sc_s = gather_columns(sc_s_local, tuple(shard_sizes), group)
-    loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True)
+    loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True, ws=student_shard.loss_workspace(sc_s.shape[0]))
     student_shard.apply(dscore[:, lo: lo + int(shard_sizes[rank])].contiguous(), Qb, qmb, arg)
     return float(loss.item())
 

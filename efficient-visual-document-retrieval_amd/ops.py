@@ -206,34 +206,72 @@ def topk(scores: torch.Tensor, k: int, idx_base: int = 0,
     return ts, ti
 
 
-def topk_with_ties(scores: torch.Tensor, k: int):
+def _order_key(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> int32 keys in evdr_topk's order (csrc/topk.hip): a larger key ranks earlier, -0.0 == +0.0, every NaN is the
+    greatest key (NaN scores rank first, like torch.topk)."""
+    u = x.contiguous().view(torch.int32)
+    key = torch.where(u < 0, u ^ 0x7FFFFFFF, u)
+    key = torch.where(u == -2147483648, torch.zeros_like(key), key)
+    return torch.where(torch.isnan(x), torch.full_like(key, 2147483647), key)
+
+
+def topk_with_ties(scores: torch.Tensor, k: int, to_host: bool = False, have=None):
     """`topk` plus what a ranking by another tie rule needs: for every row whose k-th score is shared by columns that did
-    NOT make the cut (score desc, index asc keeps the lowest indices), ALL columns with score >= the k-th score.
+    NOT make the cut (score desc, index asc keeps the lowest indices), ALL columns that rank at or above the k-th one.
 
     The reference hands every score to trec_eval (mainv2_iter_distill_infonce.py:311-317), which breaks ties by docid
     DESCENDING; a device cut by index ascending would hand it a different candidate set whenever equal scores straddle
     rank k.  With the extra columns the metric layer sees every candidate that can appear in ANY top-k under ANY tie
-    rule, so its result equals the all-pairs evaluation for every cut-off <= k.  Returns (top_scores, top_idx, extra) with
-    extra = {row: (column indices int64, their scores fp32)} as host numpy arrays -- empty when no tie is cut (the usual
-    case: one small device reduction and one sync, no further transfer)."""
-    ts, ti = topk(scores, k)
+    rule, so its result equals the all-pairs evaluation for every cut-off <= k.  Candidates are counted on the kernel's own
+    order keys (NaN = greatest, -0 = +0), so a row whose top-k holds NaNs is cut where the kernel cut it.
+    Returns (top_scores, top_idx, extra) with extra = {row: (column indices int64, their scores fp32)} as host numpy
+    arrays -- empty when no tie is cut.  to_host=True: top_scores / top_idx come back as numpy arrays too, through ONE
+    device-to-host copy that also carries the per-row candidate counts (a second copy only when a tie was cut).
+    `have` = (top_scores, top_idx) of `topk(scores, k)` when the caller has run it already."""
+    ts, ti = have if have is not None else topk(scores, k)
     extra = {}
     nq, n = scores.shape
+    count = None
     if nq and n > k:
-        kth = ts[:, k - 1:k]
-        cut = ((scores >= kth).sum(dim=1) > k).nonzero().flatten().tolist()        # NaN rows compare false: left as they are
-        for r in cut:
-            cols = (scores[r] >= kth[r]).nonzero().flatten()
-            extra[int(r)] = (cols.cpu().numpy(), scores[r, cols].float().cpu().numpy())
-    return ts, ti, extra
+        key = _order_key(scores)
+        kth = _order_key(ts[:, k - 1:k])
+        count = (key >= kth).sum(dim=1, dtype=torch.int32)
+    if to_host:
+        cols = [ts.view(torch.int32), ti] + ([count[:, None]] if count is not None else [])
+        host = torch.cat(cols, dim=1).cpu().numpy()                                # the one copy (and the one sync)
+        ts_h, ti_h = host[:, :k].view("float32"), host[:, k:2 * k]
+        cut = (host[:, 2 * k] > k).nonzero()[0] if count is not None else ()
+    else:
+        cut = (count > k).nonzero().flatten().cpu().numpy() if count is not None else ()
+    if len(cut):
+        rows = torch.as_tensor(cut, device=scores.device, dtype=torch.int64)
+        sel = key[rows] >= kth[rows]                                               # (m, n)
+        rc = sel.nonzero()
+        packed = torch.stack([rows[rc[:, 0]].to(torch.int32), rc[:, 1].to(torch.int32),
+                              scores[rows][sel].contiguous().view(torch.int32)]).cpu().numpy()
+        r_all, c_all, s_all = packed[0], packed[1].astype("int64"), packed[2].view("float32")
+        starts = (r_all[1:] != r_all[:-1]).nonzero()[0] + 1                        # nonzero() lists row-major: rows are contiguous runs
+        for a, b in zip([0, *starts.tolist()], [*starts.tolist(), len(r_all)]):
+            extra[int(r_all[a])] = (c_all[a:b], s_all[a:b])
+    return (ts_h, ti_h, extra) if to_host else (ts, ti, extra)
 
 
-_INFONCE_WS: dict = {}
+def infonce_workspace(b: int, dev) -> torch.Tensor:
+    """Workspace of the one-launch loss (`infonce_distill(..., ws=...)`): b per-row losses + the ticket word, ZEROED here.
+    The caller owns it: one per object that issues the loss (a FusedStudent), never shared between streams that may run
+    concurrently, alive as long as any captured graph holds its address.  Must not be made inside a stream capture (the
+    zero fill would only be recorded, and the first replay would find an uninitialised ticket)."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("infonce_workspace() inside a stream capture: allocate the loss workspace before capturing")
+    return torch.zeros((int(b) + 1,), dtype=torch.float32, device=dev)
 
 
 def infonce_distill(score_s: torch.Tensor, score_t: torch.Tensor, temperature: float,
-                    want_grad: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """A5 (criterion.py:56-68) + its closed-form gradient in one pass."""
+                    want_grad: bool, ws: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """A5 (criterion.py:56-68) + its closed-form gradient in one pass.  Without `ws`: the stateless two-launch form (row
+    kernel + mean kernel, scratch allocated per call).  With `ws` = `infonce_workspace(b, dev)` owned by the caller: ONE
+    launch (the last workgroup reduces the row losses; same bits) -- the workspace carries a ticket word between calls, so
+    it belongs to exactly one issuer."""
     dev = _require_cuda(score_s, score_t)
     if score_s.shape != score_t.shape or score_s.dim() != 2:
         raise RuntimeError("score_s and score_t must be (B, N) and equal-shaped")
@@ -244,14 +282,14 @@ def infonce_distill(score_s: torch.Tensor, score_t: torch.Tensor, temperature: f
     loss = torch.empty((), dtype=torch.float32, device=dev)
     grad = torch.empty_like(ss) if want_grad else None
     stream = L.current_stream_handle(dev)
-    # per-row losses + the ticket word of the one-launch form: kept per (device, stream, batch), zeroed once -- the kernel
-    # leaves the ticket at zero, and calls on one stream run one after the other
-    key = (dev.index, stream, b)
-    ws = _INFONCE_WS.get(key)
     if ws is None:
-        if len(_INFONCE_WS) > 64:
-            _INFONCE_WS.clear()
-        ws = _INFONCE_WS[key] = torch.zeros((b + 1,), dtype=torch.float32, device=dev)
+        row_loss = torch.empty((max(b, 1),), dtype=torch.float32, device=dev)
+        with L.on(dev):
+            L.check(lib.evdr_infonce_distill_fwd_bwd(L.ptr(ss), L.ptr(st), b, n, float(temperature), L.ptr(loss),
+                                                     L.ptr(grad), L.ptr(row_loss), stream))
+        return loss, grad
+    if ws.dtype != torch.float32 or ws.device != dev or ws.numel() != b + 1 or not ws.is_contiguous():
+        raise RuntimeError(f"infonce_distill: `ws` must be infonce_workspace({b}, {dev}) (got {tuple(ws.shape)} {ws.dtype} on {ws.device})")
     with L.on(dev):
         L.check(lib.evdr_infonce_distill_fwd_bwd_ws(L.ptr(ss), L.ptr(st), b, n, float(temperature), L.ptr(loss),
                                                     L.ptr(grad), L.ptr(ws), stream))

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_${1:-r01}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-other-regimes ${BENCH_EXTRA:-}"
+ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-other-regimes --no-extras ${BENCH_EXTRA:-}"
 run() { name=$1; shift; timeout -k 10 280 rocprofv3 --kernel-trace --kernel-include-regex "maxsim_fwd" --pmc "$@" --output-format csv -d /tmp/pmc_$name -o $name -- python3 $R/bench.py $ARGS > $OUT/$name.json 2> $OUT/$name.err; echo "$name exit=$?"; }
 run fetch FETCH_SIZE &&
 run write WRITE_SIZE &&

@@ -3,7 +3,7 @@
 # hash), then the bench line, rocprofv3 kernel stats of the same command, train bench + its kernel stats, nq sweep.
 # usage: bash scratch/profile_round.sh r02      (afterwards, locally: python scratch/pmc_post.py r02 -> the same derived files)
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -11,7 +11,7 @@ bash $R/scratch/pmc.sh $TAG > $O/${TAG}_pmc.log 2>&1; echo "pmc rc=$?"
 (cd $R && python3 scratch/pmc_post.py $TAG > $O/${TAG}_pmc_post.log 2>&1); echo "pmc_post rc=$?"
 cd /tmp
 python3 $R/bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err; echo "bench rc=$?"
-rm -rf /tmp/prof_b; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof_bench.err; echo "prof bench rc=$?"
+rm -rf /tmp/prof_b; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof_bench.err; echo "prof bench rc=$?"
 cp $(ls /tmp/prof_b/*/*kernel_stats.csv /tmp/prof_b/*kernel_stats.csv 2>/dev/null | head -1) $O/${TAG}_bench_kernel_stats.csv
 python3 $R/bench_train.py --steps 60 > $O/${TAG}_bench_train.json 2> $O/${TAG}_bench_train.err; echo "train rc=$?"
 rm -rf /tmp/prof_t; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -o train -- python3 $R/bench_train.py --steps 30 --only fused --no-cpu-baseline > $O/${TAG}_prof_train.json 2> $O/${TAG}_prof_train.err; echo "prof train rc=$?"

@@ -249,6 +249,41 @@ def test_graphed_step_equals_eager_fused_step(golden, with_teacher):
     assert student.steps == eager.steps == 4 and int(step.state[0].item()) == 4
 
 
+def test_two_graphed_steps_of_one_batch_size_captured_before_either_replays(golden):
+    """the loss workspace (row losses + ticket word) of the one-launch InfoNCE kernel is owned by the student and
+    zeroed OUTSIDE the capture.  Two GraphedSteps of the same batch size -- two students, both captured before either has
+    replayed -- must each find a zero ticket on their first replay and produce the eager losses; interleaved replays keep
+    doing so."""
+    import evdr_amd  # noqa: F401
+    import golden_recipes as R
+    from evdr_amd import driver, ops
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    dev = torch.device("cuda:0")
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = R.train_case("b4n8")
+    teacher = driver.TeacherScorer(l2_normalize(Pt * pmt.unsqueeze(-1)).to(dev), pmt.to(dev))
+    mk = lambda scale: driver.FusedStudent((Pbar0 * scale).to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+    eager = [mk(1.0), mk(0.5)]
+    students = [mk(1.0), mk(0.5)]
+    steps = [st.graphed(Qb.shape[0], Qb.shape[1], hp["temp"], None) for st in students]      # both captured, none replayed
+    ws = [st.loss_workspace(Qb.shape[0]) for st in students]
+    assert ws[0].data_ptr() != ws[1].data_ptr()                  # one workspace per issuer
+    assert all(int(w.view(torch.int32)[-1].item()) == 0 for w in ws)
+    gen = torch.Generator().manual_seed(11)
+    for i in range(3):
+        Qi = torch.nn.functional.normalize(torch.randn(Qb.shape, generator=gen), dim=-1)
+        sc_t = teacher.scores(Qi.to(dev), qmb.to(dev))
+        for j in (1, 0) if i % 2 else (0, 1):
+            le = float(eager[j].update(Qi.to(dev), qmb.to(dev), sc_t, hp["temp"]).item())
+            lg = float(steps[j](Qi, qmb, sc_t).item())
+            np.testing.assert_allclose(lg, le, rtol=1e-6)
+            np.testing.assert_allclose(students[j].x.cpu().numpy(), eager[j].x.cpu().numpy(), atol=2e-6)
+    assert all(int(w.view(torch.int32)[-1].item()) == 0 for w in ws)
+    with pytest.raises(RuntimeError):                            # a workspace cannot be born inside a capture
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ops.infonce_workspace(4, dev)
+
+
 def _sharded_driver_worker(rank, world, port, root, out):
     import os
     import sys

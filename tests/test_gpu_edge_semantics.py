@@ -225,6 +225,74 @@ def test_eval_retrieval_with_duplicate_pages_matches_all_pairs():
     assert got == want
 
 
+def test_topk_with_ties_counts_on_the_kernels_order_keys():
+    """a row whose top-k holds NaNs (ranked first by evdr_topk) and whose k-th score is tied beyond the cut
+    must be completed exactly like a row without NaNs; -0.0 ties +0.0; the host form (one copy) returns the same thing as
+    the device form; and the array metric path equals the dict path on the completed candidates."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import ops
+    from evdr_amd.evaluator.metrics import EvalIndex, evaluate, evaluate_topk, results_from_topk
+    g = torch.Generator().manual_seed(12)
+    nq, n, k = 10, 300, 100
+    scores = (torch.randn(nq, n, generator=g) * 1.5).round() / 2
+    scores[scores == 0] = torch.where(torch.rand(int((scores == 0).sum()), generator=g) < 0.5, -0.0, 0.0)
+    scores[1, [5, 17, 250]] = float("nan")                                # NaNs inside the top-k of a tied row
+    scores[2] = torch.randn(n, generator=g)                               # no ties, no NaN
+    scores[3] = torch.randn(n, generator=g)
+    scores[3, 7] = float("nan")                                           # NaN, no ties
+    ts, ti, extra = ops.topk_with_ties(scores.to(DEV), k)
+    ts_h, ti_h, extra_h = ops.topk_with_ties(scores.to(DEV), k, to_host=True)
+    assert np.array_equal(ts.cpu().numpy(), ts_h, equal_nan=True) and np.array_equal(ti.cpu().numpy(), ti_h)
+    assert extra.keys() == extra_h.keys() and all(np.array_equal(extra[r][0], extra_h[r][0]) and
+                                                  np.array_equal(extra[r][1], extra_h[r][1], equal_nan=True) for r in extra)
+    assert 2 not in extra and 3 not in extra and 1 in extra
+    # row 1: three NaNs rank first, then 97 more; everything tied with the 100th real score is a candidate
+    row = scores[1]
+    finite_sorted = torch.sort(row[~torch.isnan(row)], descending=True).values
+    kth = finite_sorted[k - 3 - 1]
+    want_cols = torch.nonzero(torch.isnan(row) | (row >= kth)).flatten().numpy()
+    assert np.array_equal(extra[1][0], want_cols) and len(want_cols) > k
+    for r, (cols, sc) in extra.items():
+        assert np.array_equal(sc, scores[r, cols].numpy(), equal_nan=True)
+    docids = [f"d{(i * 7919) % n:04d}" for i in range(n)]
+    qkeys = [f"q{i}" for i in range(nq)]
+    rel = {qkeys[i]: {docids[int(torch.nan_to_num(scores[i], nan=-9).argmax())]: 2, docids[(i * 31) % n]: 1} for i in range(nq)}
+    ks = [1, 3, 5, 10, 50, 70, 100]
+    want = evaluate(rel, results_from_topk(ts_h, ti_h, qkeys, docids, extra=extra_h), ks)
+    assert evaluate_topk(EvalIndex(rel, qkeys, docids, ks), ts_h, ti_h, extra_h) == want
+
+
+def test_eval_retrieval_array_path_equals_dict_path_and_reports_the_split():
+    """driver.eval_retrieval (one D2H copy, evaluate_topk) == compute_mteb_metrics over the all-pairs dict of the same device
+    scores, with multi-relevant qrels and quantised (bf16-like) ties; the optional timing split adds up."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import driver
+    from evdr_amd.evaluator.retrieval import CustomRetrievalEvaluator, score_multi_vector_masked
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    g = torch.Generator().manual_seed(13)
+    base = torch.randn(150, 30, 128, generator=g)
+    P = torch.cat([base, base[:20]])                                      # 20 duplicate pages: exact score ties
+    pm = torch.rand(170, 30, generator=g) > 0.1
+    pm[150:] = pm[:20]
+    Q = torch.nn.functional.normalize(base[:40, :10] + 0.3 * torch.randn(40, 10, 128, generator=g), dim=-1)
+    qm = torch.ones(40, 10, dtype=torch.bool)
+    docmap = {str(i): f"doc{(i * 37) % 170:03d}" for i in range(170)}
+    qs = np.array([f"query {i}" for i in range(40)], dtype=object)
+    rel = {str(qs[i]): {docmap[str(i)]: 2, docmap[str((i * 11 + 3) % 170)]: 1, docmap[str(150 + i % 20)]: 1} for i in range(40)}
+    ev = CustomRetrievalEvaluator()
+    timing = {}
+    got = driver.eval_retrieval(ev, Q.to(DEV), qm.to(DEV), P.to(DEV), pm.to(DEV), rel, docmap, qs, k=100, timing=timing)
+    again = driver.eval_retrieval(ev, Q.to(DEV), qm.to(DEV), P.to(DEV), pm.to(DEV), rel, docmap, qs, k=100)
+    sc = score_multi_vector_masked(Q.to(DEV), l2_normalize(P.to(DEV) * pm.to(DEV).unsqueeze(-1)), qm.to(DEV), pm.to(DEV)).cpu()
+    allpairs = {str(qs[i]): {docmap[str(j)]: float(sc[i, j]) for j in range(170)} for i in range(40)}
+    want = ev.compute_mteb_metrics(rel, allpairs)
+    for m in (got, again):
+        assert m.pop("latency") > 0
+        assert m == want
+    assert set(timing) == {"device_ms", "d2h_ms", "host_ms", "total_ms"} and all(v >= 0 for v in timing.values())
+    assert timing["device_ms"] + timing["d2h_ms"] + timing["host_ms"] <= timing["total_ms"] * 1.05 + 0.5
+
+
 def test_dq_is_deterministic_and_matches_the_oracle():
     """The page-segment split of the dQ kernel (training shape: 1024 pairs -> 16 segments) reduces its partial sums in a
     fixed order: bit-identical run to run, and equal to autograd of the oracle."""

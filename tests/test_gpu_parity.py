@@ -432,9 +432,9 @@ def test_a5_infonce_kernel(golden, dev):
 
 @pytest.mark.parametrize("b,n", [(1, 7), (32, 500), (300, 129)])
 def test_a5_one_launch_form_equals_two_launch_form(dev, b, n):
-    """evdr_infonce_distill_fwd_bwd_ws (row kernel whose last workgroup also takes the mean; what ops.infonce_distill calls) ==
-    evdr_infonce_distill_fwd_bwd (row kernel + mean kernel), bit for bit, call after call on one workspace (the ticket word
-    returns to zero)."""
+    """evdr_infonce_distill_fwd_bwd_ws (row kernel whose last workgroup also takes the mean; ops.infonce_distill with a
+    caller-owned workspace) == evdr_infonce_distill_fwd_bwd (row kernel + mean kernel; ops.infonce_distill without one), bit
+    for bit, call after call on one workspace (the ticket word returns to zero)."""
     from evdr_amd import _lib as L, ops
     gen = torch.Generator().manual_seed(b * 1000 + n)
     lib = L.load()
@@ -444,10 +444,15 @@ def test_a5_one_launch_form_equals_two_launch_form(dev, b, n):
         tt = torch.randn(b, n, generator=gen).to(dev)
         loss2, row2, d2 = torch.empty((), device=dev), torch.empty(b, device=dev), torch.empty(b, n, device=dev)
         L.check(lib.evdr_infonce_distill_fwd_bwd(L.ptr(ss), L.ptr(tt), b, n, 0.1, L.ptr(loss2), L.ptr(d2), L.ptr(row2), st))
-        loss1, d1 = ops.infonce_distill(ss, tt, 0.1, want_grad=True)
+        if rep == 0:
+            ws = ops.infonce_workspace(b, dev)
+        loss1, d1 = ops.infonce_distill(ss, tt, 0.1, want_grad=True, ws=ws)
         assert loss1.item() == loss2.item() and torch.equal(d1, d2)
-        ws = ops._INFONCE_WS[(dev.index, st, b)]
         assert ws.view(torch.int32)[b].item() == 0 and torch.equal(ws[:b], row2)
+        loss3, d3 = ops.infonce_distill(ss, tt, 0.1, want_grad=True)                   # stateless form
+        assert loss3.item() == loss2.item() and torch.equal(d3, d2)
+    with pytest.raises(RuntimeError):
+        ops.infonce_distill(ss, tt, 0.1, want_grad=True, ws=torch.zeros(b + 2, device=dev))
 
 
 @pytest.mark.parametrize("tag", ["b4n8", "b32n128"])

@@ -242,3 +242,72 @@ def test_results_from_topk_uses_the_tie_completion():
     assert evaluate(qrels, results_from_topk(ts, ti, ["q"], docids, extra=extra), [1, 2]) == want
     assert want["Recall"]["Recall@2"] == 1.0
     assert evaluate(qrels, results_from_topk(ts, ti, ["q"], docids), [1, 2])["Recall"]["Recall@2"] == 0.0   # the bare cut misses it
+
+
+# ---- the array metric path (evaluate_topk) == the dict entry (evaluate), bit for bit ------------------------------------
+def _device_like_topk(scores: np.ndarray, k: int):
+    """What evdr_topk + ops.topk_with_ties hand to the host, computed with numpy: top-k by (score desc with NaN first,
+    index asc) and, for rows whose k-th score is tied beyond the cut, every column ranking at or above it."""
+    nq, n = scores.shape
+    key = np.where(np.isnan(scores), np.inf, scores.astype(np.float64))
+    nanfirst = np.isnan(scores)
+    order = np.lexsort((np.broadcast_to(np.arange(n), (nq, n)), -key, ~nanfirst), axis=-1)
+    ti = order[:, :k].astype(np.int32)
+    ts = np.take_along_axis(scores, order[:, :k], 1)
+    extra = {}
+    for r in range(nq):
+        kth = ts[r, k - 1]
+        cand = np.nonzero(np.isnan(scores[r]) | (scores[r] >= kth))[0] if not np.isnan(kth) else np.nonzero(np.isnan(scores[r]))[0]
+        if len(cand) > k:
+            extra[r] = (cand.astype(np.int64), scores[r, cand])
+    return ts, ti, extra
+
+
+@pytest.mark.parametrize("nq,n,k,quant,multi,holes,nan", [
+    (50, 300, 100, 0, False, False, False),       # ViDoRe-like: one relevant page, no ties
+    (50, 300, 100, 4, False, False, False),       # quantised scores: tie runs across the cut in almost every row
+    (64, 400, 100, 3, True, False, False),        # multi-relevant qrels with graded and non-positive relevance
+    (40, 90, 100, 2, True, False, False),         # fewer pages than the largest cut-off
+    (30, 200, 100, 0, True, True, False),         # holes (idx -1) at the end of a short shard's list
+    (30, 200, 100, 5, True, False, True),         # NaN scores (ranked first by the device, last by the metric's sort)
+    (30, 200, 20, 5, True, False, False),         # device k below the largest cut-off
+])
+def test_evaluate_topk_equals_the_dict_entry(nq, n, k, quant, multi, holes, nan):
+    from evdr_amd.evaluator.metrics import EvalIndex, evaluate, evaluate_topk, results_from_topk
+    ks = [1, 3, 5, 10, 50, 70, 100]
+    for seed in range(4):
+        rng = np.random.default_rng(1000 * seed + nq + n)
+        scores = rng.standard_normal((nq, n)).astype(np.float32)
+        if quant:
+            scores = (np.round(scores * quant) / quant).astype(np.float32)
+            scores[scores == 0] = np.where(rng.random((scores == 0).sum()) < 0.5, -0.0, 0.0)      # -0.0 ties +0.0
+        if nan:
+            scores[rng.integers(0, nq, 6), rng.integers(0, n, 6)] = np.nan
+        docids = [f"doc{rng.integers(0, 10 ** 6)}_{j}" for j in range(n)]                        # string order != page order
+        qkeys = [f"q{i}" for i in range(nq)]
+        qrels = {"unanswered": {"doc0": 1}}                                                       # counts in MRR's denominator
+        for i in range(nq):
+            if i % 7 == 3:
+                continue                                                                          # a query without judgements
+            m = int(rng.integers(1, 6)) if multi else 1
+            qrels[qkeys[i]] = {docids[j]: (int(rng.integers(-1, 4)) if multi else 1) for j in rng.choice(n, m, replace=False)}
+            if multi and i % 5 == 0:
+                qrels[qkeys[i]]["not_in_corpus"] = 2
+        ts, ti, extra = _device_like_topk(scores, min(k, n))
+        if holes:
+            ti[:, -3:], ts[:, -3:], extra = -1, -np.inf, {}
+        want = evaluate(qrels, results_from_topk(ts, ti, qkeys, docids, extra=extra), ks)
+        got = evaluate_topk(EvalIndex(qrels, qkeys, docids, ks), ts, ti, extra)
+        assert got == want, (seed, got, want)
+        if quant and not holes and n > k:
+            assert extra                                                                          # the tie path really ran
+
+
+def test_evaluate_topk_with_repeated_docids_goes_through_the_dict_entry():
+    from evdr_amd.evaluator.metrics import EvalIndex, evaluate, evaluate_topk, results_from_topk
+    ts = np.array([[3.0, 2.0, 1.0]], dtype=np.float32)
+    ti = np.array([[0, 1, 2]], dtype=np.int32)
+    docids, qkeys, qrels = ["a", "b", "a"], ["q"], {"q": {"a": 1}}
+    idx = EvalIndex(qrels, qkeys, docids, [1, 3])
+    assert not idx.usable
+    assert evaluate_topk(idx, ts, ti) == evaluate(qrels, results_from_topk(ts, ti, qkeys, docids), [1, 3])
