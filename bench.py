@@ -454,7 +454,7 @@ def main():
         res = results_from_topk(ts.cpu().numpy(), ti.cpu().numpy(), [str(i) for i in range(args.queries)], docids)
         ndcg5 = CustomRetrievalEvaluator().compute_mteb_metrics(qrels, res)["NDCG"]["NDCG@5"]
         if world == 1 and not args.no_cpu_baseline:
-            n_cpu = min(4096, corpus.n_pages)
+            n_cpu = min(2048, corpus.n_pages)
             cpu_base, s_cpu = cpu_baseline_leg(shard_pages[:n_cpu], Q)
             dmax = (out[:32, :n_cpu].cpu() - s_cpu).abs().max().item()      # same inputs: the oracle as checker
             cpu_base["max_abs_diff_vs_gpu"] = dmax

@@ -245,11 +245,32 @@ def gather_rows(block: torch.Tensor, sizes) -> torch.Tensor:
     return gather_columns(flat.float(), tuple(sizes)).t().reshape((int(sum(sizes)),) + tuple(block.shape[1:])).to(block.dtype)
 
 
+LOAD_STATS: list = []           # one dict per dataset of the last run(): which pages this rank put on its GPU (tests read it)
+
+
+def _shard_docs(docs_obj, attn_obj, img_obj, lo: int, hi: int, world: int, device):
+    """(P_raw, pmask) of the pages [lo, hi) only: with world > 1 the object arrays are sliced on the host and padded to the
+    longest page of the WHOLE dump (a pass over lengths, no copy), so no rank ever holds the (N, Lmax, 128) fp32 tensor of all
+    pages."""
+    if world == 1:
+        P, pm, _ = preprocess_docs(docs_obj, attn_obj, img_obj, device)
+        return P, pm
+    docs = _as_object_array(docs_obj)
+    lmax = max(int(t.shape[0]) for t in docs)
+    d = int(docs[0].shape[1])
+    if hi <= lo:                                                    # more ranks than pages: an empty shard of the right shape
+        return (torch.zeros((0, lmax, d), dtype=torch.float32, device=device), torch.zeros((0, lmax), dtype=torch.bool, device=device))
+    cut = lambda a: None if a is None else _as_object_array(a)[lo:hi]
+    P, pm, _ = preprocess_docs(docs[lo:hi], cut(attn_obj), cut(img_obj), device, pad_to=lmax)
+    return P, pm
+
+
 def run(args) -> None:
     """Single process: the reference's loop.  Under torch.distributed (WORLD_SIZE > 1, see main): PAGE-SHARDED -- every rank
     holds the teacher and student pages [lo, hi) of its shard, the query batch is replicated, score columns are
     all-gathered (training: `sharded_*_train_one_step`; evaluation: `shard_sizes`), rank 0 logs and checkpoints."""
     set_seed(args.seed)
+    LOAD_STATS.clear()
     rank, world = _dist_context()
     device = torch.device("cuda" if args.device == "auto" else args.device)
     mapping = json.loads(Path(args.mapping_json).read_text())
@@ -264,14 +285,19 @@ def run(args) -> None:
         else:
             Q_train, qmask_train = Q_train.pin_memory(), qmask_train.pin_memory()
         Q_test, qmask_test = preprocess_queries(t_payload["query"], t_payload["query_attnmask"], device=device)
-        P_t_raw, pmask_t, _ = preprocess_docs(t_payload["documents"], t_payload["doc_attnmask"], t_payload["doc_imgmask"], device)
-        P_t_norm = l2_normalize(P_t_raw * pmask_t.unsqueeze(-1)).detach()
-        n_pages = P_t_norm.shape[0]
-        n_train = Q_train.shape[0]
+        # page-sharded run: this rank pads, uploads and normalises ONLY its pages [lo, hi) -- the object arrays are cut on the
+        # host before anything reaches the GPU (padded to the dump's longest page, so that all shards have one shape)
+        n_pages = len(t_payload["documents"])
         lo, hi = shard_range(n_pages, rank, world)
         shard_sizes = [shard_range(n_pages, r, world)[1] - shard_range(n_pages, r, world)[0] for r in range(world)] if world > 1 else None
-        if world > 1:
-            P_t_norm, pmask_t = P_t_norm[lo:hi].contiguous(), pmask_t[lo:hi].contiguous()
+        torch.cuda.reset_peak_memory_stats(device)
+        P_t_raw, pmask_t = _shard_docs(t_payload["documents"], t_payload["doc_attnmask"], t_payload["doc_imgmask"], lo, hi, world, device)
+        P_t_norm = l2_normalize(P_t_raw * pmask_t.unsqueeze(-1)).detach()
+        n_train = Q_train.shape[0]
+        stats = {"dataset": dataset, "rank": rank, "world": world, "n_pages": n_pages, "lo": lo, "hi": hi,
+                 "teacher_rows_on_device": int(P_t_raw.shape[0]),
+                 "peak_bytes_after_teacher_load": int(torch.cuda.max_memory_allocated(device))}
+        LOAD_STATS.append(stats)
         teacher = TeacherScorer(P_t_norm, pmask_t, cache_size=n_train if args.cache_teacher_scores else 0)
         del P_t_raw
         steps_per_epoch = (n_train + args.q_batch - 1) // args.q_batch
@@ -288,11 +314,10 @@ def run(args) -> None:
                                                                  Pbar_obj, attn_in, img_in)
                 if ok:
                     print(f"[align] {dataset} mf{mf}: init matched by docid")
-            Pbar_raw, pmask_s, _ = preprocess_docs(Pbar_obj, attn_in, img_in, device)
-            if Pbar_raw.shape[0] != n_pages:
-                raise ValueError(f"init doc count mismatch: got {Pbar_raw.shape[0]} vs teacher {n_pages}")
-            if world > 1:
-                Pbar_raw, pmask_s = Pbar_raw[lo:hi].contiguous(), pmask_s[lo:hi].contiguous()
+            if len(Pbar_obj) != n_pages:
+                raise ValueError(f"init doc count mismatch: got {len(Pbar_obj)} vs teacher {n_pages}")
+            Pbar_raw, pmask_s = _shard_docs(Pbar_obj, attn_in, img_in, lo, hi, world, device)
+            stats[f"student_rows_on_device_mf{mf}"] = int(Pbar_raw.shape[0])
             if args.fused_step:
                 if args.opt != "adamw":
                     raise ValueError("--fused_step implements AdamW only")

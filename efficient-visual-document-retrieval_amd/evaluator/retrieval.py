@@ -39,7 +39,8 @@ def get_torch_device(device: str = "auto") -> str:
 # call (mainv2_iter_distill_infonce.py:282-283 re-scores P_teacher_norm every step).  Their device-side preparation --
 # absmax + fp16 hi/lo split + mask packing, three passes over the pages -- is kept per tensor and reused while the tensor
 # is alive and its autograd version counter has not moved (in-place torch ops bump it; so do this package's own in-place
-# kernels).  Writes through raw pointers by other libraries are not seen: call `forget_prepared()` after such a write.
+# kernels).  Writes through raw pointers by other libraries and writes through `tensor.data` (which do not bump the
+# counter) are not seen: call `forget_prepared()` after such a write.
 _PREPARED: "collections.OrderedDict" = collections.OrderedDict()
 _PREPARED_MAX = 4                      # tensors
 _PREPARED_MAX_BYTES = 32 << 30         # of prepared planes in total (they are as large as the fp32 pages themselves)

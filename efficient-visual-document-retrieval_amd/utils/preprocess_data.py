@@ -87,12 +87,14 @@ def _to_bool_1d(arr) -> Optional[np.ndarray]:
     return a
 
 
-def pad_tokens_object(tok_list) -> Tuple[np.ndarray, np.ndarray]:
-    """object array (N,) of (Li, D) -> zero-padded (N, Lmax, D) float32 and the (N, Lmax) validity mask."""
+def pad_tokens_object(tok_list, pad_to: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """object array (N,) of (Li, D) -> zero-padded (N, Lmax, D) float32 and the (N, Lmax) validity mask.  `pad_to`: pad to
+    at least this length (a rank that loads only its page shard pads to the whole dump's longest page, so that all shards
+    have one shape)."""
     toks = _as_object_array(tok_list)
     lens = np.fromiter((int(t.shape[0]) for t in toks), dtype=np.int64, count=len(toks))
     d = int(toks[0].shape[1])
-    lmax = int(lens.max())
+    lmax = max(int(lens.max()), int(pad_to or 0))
     pad = np.zeros((len(toks), lmax, d), dtype=np.float32)
     for i, t in enumerate(toks):
         pad[i, : lens[i]] = t
@@ -116,9 +118,10 @@ def pad_mask_object(mask_list, L: int, N: int, valid: np.ndarray) -> np.ndarray:
     return out
 
 
-def preprocess_docs(documents_obj, doc_attnmask_obj, doc_imgmask_obj, device):
-    """-> (P_raw (N,L,D) fp32 NOT normalised, pmask (N,L) bool = valid & attn & img, valid (N,L) numpy bool)."""
-    pad, valid = pad_tokens_object(documents_obj)
+def preprocess_docs(documents_obj, doc_attnmask_obj, doc_imgmask_obj, device, pad_to: Optional[int] = None):
+    """-> (P_raw (N,L,D) fp32 NOT normalised, pmask (N,L) bool = valid & attn & img, valid (N,L) numpy bool).  `pad_to`: see
+    `pad_tokens_object` (not in the reference's signature; only the page-sharded driver passes it)."""
+    pad, valid = pad_tokens_object(documents_obj, pad_to)
     n, l, _ = pad.shape
     pm = valid & pad_mask_object(doc_attnmask_obj, l, n, valid) & pad_mask_object(doc_imgmask_obj, l, n, valid)
     return (torch.from_numpy(pad).to(device=device, dtype=torch.float32),

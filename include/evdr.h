@@ -98,7 +98,11 @@ int evdr_flag_nonfinite(const void* P, int dtype, const uint8_t* pmask, int64_t 
  * query token (what torch.max picks, :201) -- needed only for evdr_maxsim_bwd.
  * chunk_p of the reference is a memory knob with no numerical effect and has no counterpart.
  * lq == 1 with dense queries (the single-token "virtual queries" of mainv3_iter_liscore_QA_hardtoken.py:428-434) is
- * scored 32 queries to an MFMA tile internally; shapes and results are those of the general case. */
+ * scored 32 queries to an MFMA tile internally; shapes and results are those of the general case.
+ * Cost note: this entry PREPARES the pages on every call -- it packs pmask, scans P for NaN / Inf (one extra read of
+ * all of P: with 1-8 queries per call, where the scorer itself only streams P once, that roughly doubles the call) and,
+ * for EVDR_F32, splits P into fp16 planes.  A caller that scores the same pages more than once should prepare them once
+ * (evdr_pack_pmask + evdr_flag_nonfinite [+ evdr_split_f32]) and call evdr_maxsim_fwd_prepared. */
 size_t evdr_maxsim_fwd_workspace(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype);
 int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const uint8_t* pmask,
                     float* out, uint16_t* argmax_or_null,

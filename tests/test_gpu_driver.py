@@ -295,6 +295,9 @@ def _sharded_driver_worker(rank, world, port, root, out):
     driver.main(["--datasets", "synth", "--mapping_json", f"{root}/map.json", "--query_root", root, "--teacher_root", root,
                  "--init_root", root, "--mfs", "4", "--out_root", out, "--name", "run", "--max_steps", "10", "--eval_every", "5",
                  "--print_every", "1", "--q_batch", "32", "--fused_step", "--cache_teacher_scores"])
+    import json as _json
+    with open(os.path.join(out, f"load_stats_rank{rank}.json"), "w") as f:
+        _json.dump(driver.LOAD_STATS, f)
 
 
 def test_driver_page_sharded_two_ranks(tmp_path):
@@ -311,8 +314,18 @@ def test_driver_page_sharded_two_ranks(tmp_path):
               "--eval_every", "5", "--print_every", "1", "--q_batch", "32", "--fused_step", "--cache_teacher_scores"]
     single = tmp_path / "results_single"
     driver.main(common + ["--out_root", str(single)])
+    single_stats = dict(driver.LOAD_STATS[0])
     sharded = tmp_path / "results_sharded"
+    sharded.mkdir()
     mp.spawn(_sharded_driver_worker, args=(2, 29800 + os.getpid() % 150, str(tmp_path), str(sharded)), nprocs=2, join=True)
+    # every rank put ONLY its own pages on the GPU (teacher and student), and its peak device memory while loading the
+    # teacher shows it: the whole-dump padded tensor never existed on a rank
+    assert single_stats["teacher_rows_on_device"] == single_stats["n_pages"] == 48
+    for r in range(2):
+        st = json.loads((sharded / f"load_stats_rank{r}.json").read_text())[0]
+        assert (st["rank"], st["world"], st["n_pages"]) == (r, 2, 48) and (st["lo"], st["hi"]) == (24 * r, 24 * r + 24)
+        assert st["teacher_rows_on_device"] == 24 and st["student_rows_on_device_mf4"] == 24
+        assert st["peak_bytes_after_teacher_load"] < 0.8 * single_stats["peak_bytes_after_teacher_load"]
 
     def parse(d):
         lines = (d / "run" / "mf4" / "synth" / "train.log").read_text().splitlines()
