@@ -25,7 +25,7 @@ LT, LS, LQ, D = 1030, 206, 32, 128
 MFMA_F16_PEAK, MFMA_F32_PEAK, HBM_PEAK = 2500.0, 157.3, 8000.0    # TFLOP/s dense fp16/bf16, TFLOP/s fp32 MFMA, GB/s (MI355X_MICROARCH.md)
 PLANE_PRODUCTS = 3                                                 # lo*hi + hi*lo + hi*hi per fp32 product (csrc/maxsim_fwd16.hip)
 ALL_KINDS = ["call_pattern", "resident", "cached", "fused", "fused_cached", "fused_nosync", "fused_cached_nosync", "fused_graph",
-             "fused_cached_graph"]
+             "fused_cached_graph", "fused_overlap", "fused_overlap_nosync"]
 
 
 def eager_maxsim(Q, P, qmask, pmask, chunk_p=64):
@@ -82,6 +82,8 @@ def time_mode(inp, kind: str, steps: int, warmup: int):
             return float(graphed(Qb, qmb, teacher.scores(Qb, qmb, idx)).item())
         if kind in ("fused", "fused_cached"):
             return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached" else None)
+        if kind in ("fused_overlap", "fused_overlap_nosync"):   # student forward on a second stream beside the teacher forward
+            return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, sync=kind == "fused_overlap", overlap=True)
         if kind in ("fused_nosync", "fused_cached_nosync"):     # loss stays on the device: no host sync inside the timed loop
             return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached_nosync" else None,
                                                sync=False)

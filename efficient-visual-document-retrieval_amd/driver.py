@@ -513,12 +513,13 @@ class FusedStudent:
         self._planes_of = (self.x, self.x._version)           # the kernel left the planes of the UPDATED x
 
     def update(self, Qb, qmb, sc_t, temp: float, state: Optional[torch.Tensor] = None, qplanes=None,
-               loss_to_host: bool = False) -> torch.Tensor:
+               loss_to_host: bool = False, scored=None) -> torch.Tensor:
         """One step given the teacher scores; returns the loss as a device scalar (no host sync).  With `state` (a
         device-side step counter, ops.adamw_state) nothing in the step depends on a host scalar: graph-capturable.
         `loss_to_host`: the loss is also copied to pinned host memory BEFORE the update kernel is launched
-        (`wait_loss()` returns it as soon as that copy has landed, while the update still runs)."""
-        sc_s, arg = self.scores(Qb, qmb, qplanes)
+        (`wait_loss()` returns it as soon as that copy has landed, while the update still runs).  `scored` = (scores,
+        argmax) of `self.scores(Qb, qmb)` when the caller has issued the student forward already (on another stream)."""
+        sc_s, arg = scored if scored is not None else self.scores(Qb, qmb, qplanes)
         loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True, ws=self.loss_workspace(sc_s.shape[0]))
         if loss_to_host:
             if self._loss_host is None:
@@ -596,16 +597,37 @@ class GraphedStep:
 
 
 def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStudent, temp: float,
-                         qidx: Optional[torch.Tensor] = None, sync: bool = True):
+                         qidx: Optional[torch.Tensor] = None, sync: bool = True, overlap: bool = False):
     """One fused update.  sync=True returns float(loss) like the reference's train_one_step (one host wait per step, for the
     loss only: the parameter update may still be running when it returns -- later work on the stream is ordered behind it);
     sync=False returns the loss as a device scalar and leaves the stream running, so that the host queues the next step
-    while this one executes (read the loss when it is logged)."""
+    while this one executes (read the loss when it is logged).
+    overlap=True issues the student forward on a second stream beside the teacher forward (the two are independent; the
+    loss waits for both).  Measured: no gain on MI355X -- both kernels fill the chip with one 256-register, full-LDS
+    workgroup per CU, so they cannot share a CU and only trade places; kept as an option for the A/B."""
     device = student.x.device
     Qb = Qb.to(device, non_blocking=True).float()
     qmb = qmb.to(device, non_blocking=True)
     qplanes = ops.split_f32(Qb)                                      # once per step, shared by teacher and student
-    loss = student.update(Qb, qmb, teacher.scores(Qb, qmb, qidx, qplanes=qplanes), temp, qplanes=qplanes, loss_to_host=sync)
+    scored = None
+    if overlap:
+        main = torch.cuda.current_stream(device)
+        if getattr(student, "_side", None) is None:
+            student._side = torch.cuda.Stream(device=device)
+            student._ev_in, student._ev_out = torch.cuda.Event(), torch.cuda.Event()
+        student._ev_in.record(main)
+        with torch.cuda.stream(student._side):
+            student._side.wait_event(student._ev_in)
+            scored = student.scores(Qb, qmb, qplanes)
+            student._ev_out.record(student._side)
+        for t in (Qb, qmb, qplanes[0], qplanes[1]):                  # made on the main stream, read on the side stream
+            t.record_stream(student._side)
+    sc_t = teacher.scores(Qb, qmb, qidx, qplanes=qplanes)
+    if overlap:
+        main.wait_event(student._ev_out)
+        for t in scored:                                             # made on the side stream, read on the main stream
+            t.record_stream(main)
+    loss = student.update(Qb, qmb, sc_t, temp, qplanes=qplanes, loss_to_host=sync, scored=scored)
     # sync: the loss left for the host before the update kernel was launched, so float(loss) is back while that kernel (a
     # seventh of the step) still runs and the caller's next launches queue up behind it instead of behind an idle GPU
     return student.wait_loss() if sync else loss

@@ -249,6 +249,28 @@ def test_graphed_step_equals_eager_fused_step(golden, with_teacher):
     assert student.steps == eager.steps == 4 and int(step.state[0].item()) == 4
 
 
+def test_fused_step_with_the_student_forward_on_a_second_stream(golden):
+    """fused_train_one_step(overlap=True): the student forward is issued on a side stream beside the teacher forward; same
+    losses and parameters as the one-stream step, step after step (stream hand-over of planes, scores and argmax)."""
+    import evdr_amd  # noqa: F401
+    import golden_recipes as R
+    from evdr_amd import driver
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    dev = torch.device("cuda:0")
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = R.train_case("b32n128")
+    teacher = driver.TeacherScorer(l2_normalize(Pt * pmt.unsqueeze(-1)).to(dev), pmt.to(dev))
+    a = driver.FusedStudent(Pbar0.to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+    b = driver.FusedStudent(Pbar0.to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+    gen = torch.Generator().manual_seed(5)
+    for i in range(6):
+        Qi = Qb if i == 0 else torch.nn.functional.normalize(torch.randn(Qb.shape, generator=gen), dim=-1)
+        la = driver.fused_train_one_step(Qi.to(dev), qmb.to(dev), teacher, a, hp["temp"])
+        lb = driver.fused_train_one_step(Qi.to(dev), qmb.to(dev), teacher, b, hp["temp"], overlap=True, sync=(i % 2 == 0))
+        assert la == float(lb)
+        torch.cuda.synchronize()
+        assert torch.equal(a.x, b.x)
+
+
 def test_two_graphed_steps_of_one_batch_size_captured_before_either_replays(golden):
     """the loss workspace (row losses + ticket word) of the one-launch InfoNCE kernel is owned by the student and
     zeroed OUTSIDE the capture.  Two GraphedSteps of the same batch size -- two students, both captured before either has
