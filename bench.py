@@ -142,7 +142,7 @@ def self_launch(n: int, backend: str, need_gpus: bool = True) -> int:
     import socket
     import subprocess
     ndev = visible_gpu_count()
-    if need_gpus and backend == "nccl" and ndev is not None and ndev < n:
+    if need_gpus and backend == "nccl" and ndev is not None and ndev < n and not os.environ.get("EVDR_BENCH_ALLOW_SHARED_GPU"):
         print(f"bench.py: --gpus {n} with backend nccl needs {n} visible GPUs, found {ndev} "
               f"(--backend gloo rehearses N>1 on fewer GPUs)", file=sys.stderr)
         return 2

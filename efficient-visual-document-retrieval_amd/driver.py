@@ -603,8 +603,9 @@ def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStuden
     sync=False returns the loss as a device scalar and leaves the stream running, so that the host queues the next step
     while this one executes (read the loss when it is logged).
     overlap=True issues the student forward on a second stream beside the teacher forward (the two are independent; the
-    loss waits for both).  Measured: no gain on MI355X -- both kernels fill the chip with one 256-register, full-LDS
-    workgroup per CU, so they cannot share a CU and only trade places; kept as an option for the A/B."""
+    loss waits for both).  Measured on MI355X (profiles/r03_experiments.txt): 0.4625 ms per step against 0.438 -- SLOWER.
+    Both kernels fill the chip with one 256-register workgroup per CU that takes most of the LDS, so workgroups of the two
+    launches cannot share a CU and only trade places, and the events cost host time; kept as an option for the A/B only."""
     device = student.x.device
     Qb = Qb.to(device, non_blocking=True).float()
     qmb = qmb.to(device, non_blocking=True)

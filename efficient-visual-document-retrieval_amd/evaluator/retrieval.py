@@ -86,6 +86,9 @@ class _MaxSimMasked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Q, P, qmask, pmask):
         need_dq, need_dp = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ctx.width = int(Q.shape[-1]) if Q.dim() == 3 else ops.D
+        if Q.dim() == 3 and P.dim() == 3 and Q.shape[-1] == P.shape[-1] and 0 < Q.shape[-1] < ops.D:
+            Q, P = ops.pad_width(Q), ops.pad_width(P)     # narrower embeddings ride on zero columns (exact); gradients are cut back
         both_bf16 = P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16
         frozen = (not need_dp and P.is_cuda and P.dim() == 3 and Q.dim() == 3 and P.shape[-1] == ops.D and Q.shape[-1] == ops.D
                   and (both_bf16 or P.dtype != torch.bfloat16) and not (both_bf16 and need_dq)
@@ -110,9 +113,9 @@ class _MaxSimMasked(torch.autograd.Function):
         npg, lp, _ = ctx.p_shape
         dQ = dP = None
         if ctx.needs_input_grad[1]:
-            dP = ops.maxsim_backward(g, Q, qmask, pmask, arg, npg, lp).to(ctx.p_dtype)
+            dP = ops.maxsim_backward(g, Q, qmask, pmask, arg, npg, lp)[..., :ctx.width].to(ctx.p_dtype)
         if ctx.needs_input_grad[0]:
-            dQ = ops.maxsim_backward_q(g, P, qmask, pmask, arg, Q.shape[0], Q.shape[1]).to(ctx.q_dtype)
+            dQ = ops.maxsim_backward_q(g, P, qmask, pmask, arg, Q.shape[0], Q.shape[1])[..., :ctx.width].to(ctx.q_dtype)
         return dQ, dP, None, None
 
 

@@ -39,6 +39,18 @@ def _mask_u8(m: Optional[torch.Tensor], shape, dev) -> Optional[torch.Tensor]:
     return m.to(device=dev).bool().contiguous()
 
 
+def pad_width(x: torch.Tensor) -> torch.Tensor:
+    """(..., d) -> (..., 128) with zero columns appended when d < 128 (the kernels are built for the ColPali / ColQwen
+    projection width; a zero column contributes an exact 0 to every dot product, so scores, arg-max and the first d columns
+    of every gradient are those of the narrow tensors).  Wider embeddings are not supported."""
+    d = x.shape[-1]
+    if d == D:
+        return x
+    if d > D or d == 0:
+        raise NotImplementedError(f"embedding width {d} unsupported (kernels are built for widths up to {D})")
+    return torch.nn.functional.pad(x, (0, D - d))
+
+
 def workspace(nbytes: int, dev) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
 
@@ -98,10 +110,9 @@ def maxsim_forward(Q: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Tenso
     dev = _require_cuda(Q, P)
     if Q.dim() != 3 or P.dim() != 3 or Q.shape[-1] != P.shape[-1]:
         raise RuntimeError(f"expected Q (Nq,Lq,D) and P (Np,Lp,D), got {tuple(Q.shape)} and {tuple(P.shape)}")
+    Q, P = pad_width(Q), pad_width(P)                 # narrower embeddings: zero columns add exact zeros to every dot product
     nq, lq, d = Q.shape
     npg, lp, _ = P.shape
-    if d != D:
-        raise NotImplementedError(f"embedding width {d} unsupported (kernels are built for {D})")
     out = torch.empty((nq, npg), dtype=torch.float32, device=dev)
     arg = torch.empty((nq, npg, lq), dtype=torch.int16, device=dev) if want_argmax else None
     if nq == 0 or npg == 0:

@@ -266,9 +266,10 @@ def test_fused_step_with_the_student_forward_on_a_second_stream(golden):
         Qi = Qb if i == 0 else torch.nn.functional.normalize(torch.randn(Qb.shape, generator=gen), dim=-1)
         la = driver.fused_train_one_step(Qi.to(dev), qmb.to(dev), teacher, a, hp["temp"])
         lb = driver.fused_train_one_step(Qi.to(dev), qmb.to(dev), teacher, b, hp["temp"], overlap=True, sync=(i % 2 == 0))
-        assert la == float(lb)
+        np.testing.assert_allclose(float(lb), la, rtol=1e-6)
         torch.cuda.synchronize()
-        assert torch.equal(a.x, b.x)
+        # not bit-equal even between two one-stream runs: the backward gather adds a row's terms in scatter order
+        np.testing.assert_allclose(b.x.cpu().numpy(), a.x.cpu().numpy(), atol=2e-6)
 
 
 def test_two_graphed_steps_of_one_batch_size_captured_before_either_replays(golden):

@@ -66,3 +66,43 @@ def test_layouts_fp32(nq):
         assert torch.equal(arg.cpu().to(torch.int32) & 0xFFFF, warg.to(torch.int32)), f"{name} nq={nq}: argmax"
         s0, _ = ops.maxsim_forward(Q.to(DEV), P.to(DEV), qm.to(DEV), pm.to(DEV))
         np.testing.assert_allclose(s0.cpu().numpy(), want.numpy(), atol=1e-4, rtol=0, err_msg=f"{name} nq={nq} (no argmax)")
+
+
+@pytest.mark.parametrize("d", [32, 64, 96, 100])
+def test_embedding_widths_below_128(d):
+    """The reference scores any embedding width (evaluator/retrieval.py:166-213); the kernels are built for 128, and narrower
+    embeddings ride on zero columns, which add exact zeros to every dot product: scores, arg-max and gradients (w.r.t. pages
+    and queries, cut back to d columns) against the oracle on the narrow tensors; the list scorer too.  Wider embeddings raise."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd.evaluator.retrieval import BaseVisualRetrieverProcessor, score_multi_vector_masked
+    gen = torch.Generator().manual_seed(300 + d)
+    nq, lq, npg, lp = 9, 20, 30, 77
+    Q = torch.nn.functional.normalize(torch.randn(nq, lq, d, generator=gen), dim=-1)
+    P = torch.nn.functional.normalize(torch.randn(npg, lp, d, generator=gen), dim=-1)
+    qm = torch.rand(nq, lq, generator=gen) > 0.2
+    pm = torch.rand(npg, lp, generator=gen) > 0.2
+    pm[4] = False
+    up = torch.randn(nq, npg, generator=gen)
+    Qo, Po = Q.clone().requires_grad_(True), P.clone().requires_grad_(True)
+    so = O.maxsim_masked(Qo, Po, qm, pm)
+    so.backward(up)
+    Qd, Pd = Q.to(DEV).requires_grad_(True), P.to(DEV).requires_grad_(True)
+    s = score_multi_vector_masked(Qd, Pd, qm.to(DEV), pm.to(DEV))
+    s.backward(up.to(DEV))
+    np.testing.assert_allclose(s.detach().cpu().numpy(), so.detach().numpy(), atol=1e-4, rtol=0)
+    assert Pd.grad.shape == P.shape and Qd.grad.shape == Q.shape
+    np.testing.assert_allclose(Pd.grad.cpu().numpy(), Po.grad.numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(Qd.grad.cpu().numpy(), Qo.grad.numpy(), atol=2e-5, rtol=1e-5)
+    with torch.no_grad():                                            # frozen pages (prepared once per tensor) and bf16
+        s2 = score_multi_vector_masked(Q.to(DEV), P.to(DEV), qm.to(DEV), pm.to(DEV))
+        np.testing.assert_allclose(s2.cpu().numpy(), so.detach().numpy(), atol=1e-4, rtol=0)
+        sb = score_multi_vector_masked(Q.bfloat16().to(DEV), P.bfloat16().to(DEV), qm.to(DEV), pm.to(DEV))
+        want_b = O.maxsim_masked(Q.bfloat16().float(), P.bfloat16().float(), qm, pm)
+        np.testing.assert_allclose(sb.cpu().numpy(), want_b.numpy(), atol=1e-4, rtol=0)
+    qs = [Q[i, : 3 + i] for i in range(5)]
+    ps = [P[j, : 10 + 3 * j] for j in range(7)]
+    got = BaseVisualRetrieverProcessor.score_multi_vector(qs, ps, batch_size=4, device=DEV)
+    np.testing.assert_allclose(got.numpy(), O.maxsim_unmasked_lists(qs, ps, batch_size=4).numpy(), atol=1e-4, rtol=0)
+    with pytest.raises(NotImplementedError):
+        score_multi_vector_masked(torch.zeros(2, 3, 256, device=DEV), torch.zeros(2, 5, 256, device=DEV),
+                                  torch.ones(2, 3, device=DEV), torch.ones(2, 5, device=DEV))
