@@ -153,6 +153,48 @@ def merge_candidates(scores: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[t
     return ops.topk(scores, k, idx_map=idx)
 
 
+def tie_candidates(local_scores: torch.Tensor, idx_base: int, kth_scores: torch.Tensor, k: int, group=None):
+    """Tie completion across shards (the page-sharded form of `ops.topk_with_ties`): for every query row whose GLOBAL k-th
+    score is shared by pages that did not make the merged cut, all pages of ALL shards that rank at or above it --
+    {row: (global page indices int64 ascending, scores fp32)} as host numpy arrays, the same on every rank.
+    local_scores (nq, n_local): this rank's score block; kth_scores (nq,): the merged top-k's last column.
+    One all-reduce of nq int32 counts (always); an object all-gather of the tied triples only when some row is cut.  The
+    metric layer then ranks the tied candidates by trec_eval's rule (docid descending) exactly as the reference's all-pairs
+    evaluation would (mainv2_iter_distill_infonce.py:311-319)."""
+    import numpy as np
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    nq = local_scores.shape[0]
+    key = ops._order_key(local_scores) if local_scores.shape[1] else local_scores.new_zeros((nq, 0), dtype=torch.int32)
+    kth = ops._order_key(kth_scores.reshape(nq, 1).to(local_scores.device))
+    total = (key >= kth).sum(dim=1, dtype=torch.int32)
+    if multi:
+        if dist.get_backend(group) == "gloo" and total.is_cuda:
+            host = total.cpu()
+            dist.all_reduce(host, group=group)
+            total = host
+        else:
+            dist.all_reduce(total, group=group)
+    cut = (total > k).nonzero().flatten().to(local_scores.device)
+    if cut.numel() == 0:
+        return {}
+    sel = key[cut] >= kth[cut]
+    rc = sel.nonzero()
+    mine = (cut[rc[:, 0]].cpu().numpy().astype(np.int64), (rc[:, 1] + int(idx_base)).cpu().numpy().astype(np.int64),
+            local_scores[cut][sel].float().cpu().numpy())
+    parts = [mine]
+    if multi:
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, mine, group=group)
+    rows = np.concatenate([p[0] for p in parts])
+    cols = np.concatenate([p[1] for p in parts])
+    sc = np.concatenate([p[2] for p in parts])
+    order = np.lexsort((cols, rows))                                   # by row, then global page index (shards are contiguous)
+    rows, cols, sc = rows[order], cols[order], sc[order]
+    starts = np.flatnonzero(rows[1:] != rows[:-1]) + 1
+    return {int(rows[a]): (cols[a:b], sc[a:b]) for a, b in zip([0, *starts.tolist()], [*starts.tolist(), len(rows)])}
+
+
 class ShardedRetriever:
     """Late-interaction retrieval over a page-sharded corpus: local MaxSim + top-k, one all-gather, merge."""
 
@@ -160,10 +202,26 @@ class ShardedRetriever:
         self.shard = shard
         self.group = group
 
-    def search(self, Q: torch.Tensor, qmask: Optional[torch.Tensor], k: int = 100) -> Tuple[torch.Tensor, torch.Tensor]:
+    def search(self, Q: torch.Tensor, qmask: Optional[torch.Tensor], k: int = 100, with_ties: bool = False):
+        """(top_scores, top_idx) of the whole corpus, (score desc, global index asc), identical on every rank.  with_ties=True
+        also returns `extra` (see `tie_candidates`): the candidates a metric with another tie rule needs when equal scores
+        straddle rank k -- (top_scores, top_idx, extra); it keeps the shard's score block (nq x n_local fp32) for one more pass."""
         import torch.distributed as dist
-        ls, li = self.shard.topk(Q, qmask, k)
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
-            return ls, li
-        sc, ix = gather_candidates(ls, li, self.group)
-        return merge_candidates(sc, ix, k)
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if not with_ties:
+            ls, li = self.shard.topk(Q, qmask, k)
+            if not multi:
+                return ls, li
+            sc, ix = gather_candidates(ls, li, self.group)
+            return merge_candidates(sc, ix, k)
+        scores = self.shard.score(Q, qmask)
+        if self.shard.n_pages:
+            ls, li = ops.topk(scores, min(k, self.shard.n_pages), idx_base=self.shard.idx_base)
+            if ls.shape[1] < k:                                        # a shard shorter than k: holes at the end, like evdr_maxsim_topk
+                pad = k - ls.shape[1]
+                ls = torch.cat([ls, ls.new_full((ls.shape[0], pad), float("-inf"))], dim=1)
+                li = torch.cat([li, li.new_full((li.shape[0], pad), -1)], dim=1)
+        else:
+            ls, li = self.shard.topk(Q, qmask, k)
+        ts, ti = merge_candidates(*gather_candidates(ls, li, self.group), k) if multi else (ls, li)
+        return ts, ti, tie_candidates(scores, self.shard.idx_base, ts[:, k - 1], k, self.group)

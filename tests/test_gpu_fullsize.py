@@ -162,6 +162,20 @@ def test_rccl_exchange_single_rank(dev):
         la = driver.sharded_fused_train_one_step(Qb, qmb, teacher, a, hp["temp"], (Pt.shape[0],))
         lb = driver.fused_train_one_step(Qb, qmb, teacher, b, hp["temp"])
         assert abs(la - lb) <= 1e-6 * abs(lb) and torch.allclose(a.x, b.x, atol=1e-6)
+        # tie completion of the sharded retriever through RCCL's all-reduce / object gather at world = 1: duplicate pages
+        from evdr_amd import ops
+        from evdr_amd.corpus import PageCorpus, ShardedRetriever
+        base = torch.nn.functional.normalize(torch.randn(90, 40, 128, generator=g), dim=-1).bfloat16()
+        P = torch.cat([base, base[:1].repeat(60, 1, 1)]).to(dev)           # page 0 sixty-one times: ties across rank k = 50
+        Qd = base[:7, :16].contiguous().to(dev)
+        corpus = PageCorpus.from_tensor(P, None, idx_base=1000)
+        ts, ti, extra = ShardedRetriever(corpus).search(Qd, None, 50, with_ties=True)
+        ws, wi, wextra = ops.topk_with_ties(corpus.score(Qd, None), 50)
+        assert torch.equal(ts, ws) and torch.equal(ti, wi + 1000) and extra.keys() == wextra.keys() and len(extra) >= 1
+        for r in extra:
+            assert np.array_equal(extra[r][0], wextra[r][0] + 1000) and np.array_equal(extra[r][1], wextra[r][1])
+        ps, pi = ShardedRetriever(corpus).search(Qd, None, 50)
+        assert torch.equal(ps, ts) and torch.equal(pi, ti)
     finally:
         dist.destroy_process_group()
 
