@@ -1,5 +1,7 @@
 """One-off fuzz of the forward kernels against the oracle: many seeds of tests/test_gpu_random_sweep.py's case generator plus
-1030-patch range/hole layouts with random query counts.  usage: python scratch/fuzz_fwd.py <first_seed> <count>"""
+1030-patch range/hole layouts with random query counts.  usage: python scratch/fuzz_fwd.py <first_seed> <count> [long]
+`long` (round 3): every case is a long-page case -- lp drawn from 1057 ... 65535 (random lengths, powers of two and their neighbours,
+the ABI bound), range / hole layouts whose range may start beyond patch 4095, few pages."""
 import os, sys, numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -8,12 +10,18 @@ from evdr_amd import ops
 from oracle import maxsim_oracle as O
 import test_gpu_random_sweep as T
 dev = "cuda:0"; s0, n = int(sys.argv[1]), int(sys.argv[2]); bad = 0
+LONG = len(sys.argv) > 3 and sys.argv[3] == "long"
 torch.set_num_threads(16)
 for seed in range(s0, s0 + n):
     Q, P, qm, pm = T._case(seed)
-    if seed % 3 == 0:                                   # long pages with range / hole layouts and random query counts
+    if seed % 3 == 0 or LONG:                           # long pages with range / hole layouts and random query counts
         g = torch.Generator().manual_seed(seed)
         nq = int(torch.randint(1, 45, (1,), generator=g)); npg = int(torch.randint(1, 20, (1,), generator=g)); lp = [1030, 1024, 1056, 993, 513][seed % 5]
+        if LONG:
+            lp = [int(torch.randint(1057, 9000, (1,), generator=g)), 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 16385, 32767, 32769,
+                  int(torch.randint(9000, 65536, (1,), generator=g)), 65535][seed % 14]
+            npg = int(torch.randint(1, 6 if lp > 9000 else 12, (1,), generator=g))
+            nq = int(torch.randint(1, 20 if lp > 9000 else 45, (1,), generator=g))
         Q = torch.nn.functional.normalize(torch.randn(nq, 32, 128, generator=g), dim=-1).bfloat16()
         P = torch.nn.functional.normalize(torch.randn(npg, lp, 128, generator=g), dim=-1).bfloat16()
         a = torch.randint(0, lp, (npg,), generator=g); b = torch.randint(0, lp + 1, (npg,), generator=g)
