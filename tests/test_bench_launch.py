@@ -57,9 +57,10 @@ def test_world_size_mismatch_and_missing_gpus_fail_loudly():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """The last committed bench line (profiles/r02_bench_n1.json, written by `python bench.py` on an MI355X) carries every field
-    the driver's contract names, the roofline object of the dominant kernel and the CPU baseline."""
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")))
+    """The last committed bench line (profiles/r03_bench_n1.json, written by `python bench.py` on an MI355X) carries every field
+    the driver's contract names, the roofline object of the dominant kernel, the CPU baseline and (round 3) the training-step,
+    evaluation and phase records."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in rec, key
@@ -80,9 +81,9 @@ def test_committed_bench_line_follows_the_contract():
         t = json.loads(raw)
         assert t["kernel"] == r["kernel"] and t["queries"] == rec["config"]["queries_per_step"] and t["pages_per_gpu"] == rec["config"]["pages"]
         assert r["traffic"] == t["hbm_bytes_per_launch"] >= r["algorithmic_bytes_per_launch"]
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
         assert pmc["hbm_bytes_per_launch"] == t["hbm_bytes_per_launch"]
-    stats = open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv")).read().splitlines()
+    stats = open(os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")).read().splitlines()
     top = next(ln for ln in stats[1:] if "maxsim_fwd16s_kernel<4, 1, false, 8" in ln)
     avg_ms = float(top.split('",')[1].split(",")[2]) / 1e6
     assert abs(avg_ms - r["kernel_ms"]) < 0.01 * r["kernel_ms"]           # rocprofv3's average agrees with the HIP-event time of the line
@@ -90,3 +91,23 @@ def test_committed_bench_line_follows_the_contract():
         assert o["bound"] == "hbm" and o["peak"] == 8000.0 and 0.3 < o["frac"] < 1.0
     c = rec["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["cores"] >= 1 and c["max_abs_diff_vs_gpu"] < 1e-4
+    assert "median of 3" in c["sample"] and "2048 pages" in c["sample"]
+    # round 3: the training half (configs[4]), the evaluation (configs[1]) and the phase split ride in the same line
+    t = rec["train_step"]
+    assert set(t["results"]) == {"call_pattern", "fused", "fused_cached"} and t["config"]["pages"] == 500
+    for r_ in t["roofline"][:2]:
+        assert r_["executed_flop_per_launch"] == 3 * r_["algorithmic_flop_per_launch"] and "EXECUTED" in r_["frac_basis"]
+        assert abs(r_["frac"] - r_["executed_flop_per_launch"] / (r_["kernel_ms"] * 1e-3) / 1e12 / 2500.0) < 1e-9
+        assert abs(r_["algorithmic_tflops"] - r_["algorithmic_flop_per_launch"] / (r_["kernel_ms"] * 1e-3) / 1e12) < 1e-6
+    assert t["roofline"][2]["bound"] == "hbm" and t["cpu_baseline"]["kind"] == "port" and t["cpu_baseline"]["sample_pages"] <= 500
+    e = rec["eval"]
+    for name in ("bf16", "fp32"):
+        assert e[name]["ndcg_at_5"] == 1.0 and e[name]["device_ms"] + e[name]["d2h_ms"] + e[name]["host_ms"] <= e[name]["total_ms"]
+    assert e["bf16"]["total_ms"] <= 5.0                                   # configs[1] end to end
+    ph = rec["phases"]
+    assert set(ph["rank0"]) == {"score_ms", "topk_ms"} and abs(ph["rank0"]["score_ms"] - r["kernel_ms"]) < 0.02 * r["kernel_ms"]
+    assert rec["dist"]["ranks_seen"] == 1 and rec["dist"]["pages_per_rank"] == rec["config"]["pages"]
+    # and the standalone training bench of the same call agrees with the line's record within box noise
+    bt = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_train.json")))
+    for mode in ("call_pattern", "fused", "fused_cached"):
+        assert abs(bt["results"][mode]["ms_per_step"] - t["results"][mode]["ms_per_step"]) < 0.08 * bt["results"][mode]["ms_per_step"]
