@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 LT, LS, LQ, D = 1030, 206, 32, 128
 MFMA_F16_PEAK, MFMA_F32_PEAK, HBM_PEAK = 2500.0, 157.3, 8000.0    # TFLOP/s dense fp16/bf16, TFLOP/s fp32 MFMA, GB/s (MI355X_MICROARCH.md)
 PLANE_PRODUCTS = 3                                                 # lo*hi + hi*lo + hi*hi per fp32 product (csrc/maxsim_fwd16.hip)
-ALL_KINDS = ["call_pattern", "resident", "cached", "fused", "fused_cached", "fused_nosync", "fused_cached_nosync", "fused_graph",
+ALL_KINDS = ["call_pattern", "call_pattern_torch_adamw", "resident", "cached", "fused", "fused_cached", "fused_nosync", "fused_cached_nosync", "fused_graph",
              "fused_cached_graph", "fused_overlap", "fused_overlap_nosync"]
 
 
@@ -62,9 +62,12 @@ def time_mode(inp, kind: str, steps: int, warmup: int):
     order = torch.arange(64 * B)
     order_dev = order.to(inp["dev"])
     param = torch.nn.Parameter(Pbar0.clone())
-    opt = torch.optim.AdamW([param], lr=1e-3, weight_decay=1e-2)
+    from evdr_amd.utils.utils import set_optimizer
+    # the scripts take their optimizer from utils.set_optimizer (mainv2_iter_distill_infonce.py:127): the drop-in's is AdamW on a
+    # one-pass update kernel; "call_pattern_torch_adamw" keeps torch's own foreach AdamW for the A/B
+    opt = torch.optim.AdamW([param], lr=1e-3, weight_decay=1e-2) if kind == "call_pattern_torch_adamw" else set_optimizer("adamw", param, 1e-3, 1e-2)
     cached = kind in ("cached", "fused_cached", "fused_cached_graph", "fused_cached_nosync")
-    teacher = driver.TeacherScorer(Pt, pmt, cache_size=Qall.shape[0] if cached else 0) if kind not in ("call_pattern", "eager") else None
+    teacher = driver.TeacherScorer(Pt, pmt, cache_size=Qall.shape[0] if cached else 0) if kind not in ("call_pattern", "call_pattern_torch_adamw", "eager") else None
     student = driver.FusedStudent(Pbar0.clone(), pms, lr=1e-3, weight_decay=1e-2) if kind.startswith("fused") else None
     graphed = student.graphed(B, LQ, 0.1, None if cached else teacher) if kind.endswith("_graph") else None
 
@@ -214,7 +217,8 @@ def measure(pages: int = 500, batch: int = 32, steps: int = 50, warmup: int = 25
     return {"config": {"workload": "mainv2_iter_distill_infonce step (BASELINE.json configs[4])", "pages": pages,
                        "batch_queries": batch, "teacher_patches": LT, "student_patches": LS, "steps": steps, "warmup": warmup},
             "dtype": "f32 (fp16 hi/lo split MFMA)",
-            "modes": {"call_pattern": "the drop-in functions called exactly like the reference's train_one_step (autograd + torch AdamW)",
+            "modes": {"call_pattern": "the drop-in functions called exactly like the reference's train_one_step (autograd; the optimizer is what utils.set_optimizer returns: AdamW on the one-pass update kernel)",
+                      "call_pattern_torch_adamw": "the same with torch.optim.AdamW's own (foreach) step",
                       "fused": "float(loss) returned every step, like the reference's train_one_step (one host wait per step, for the loss only: it is copied out before the update kernel is launched)",
                       "fused_nosync": "what driver.py's --fused_step loop does between log lines: losses stay on the device until a line is due",
                       "*_cached": "teacher scores from the per-query cache (frozen teacher)"},

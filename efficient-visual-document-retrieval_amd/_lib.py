@@ -33,6 +33,7 @@ SIGNATURES = {
     "evdr_maxsim_bwd_adamw_planes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                                _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
     "evdr_adamw_advance": (C.c_int, [_vp, _f32, _f32, _vp]),
+    "evdr_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _vp]),
     "evdr_l2norm_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
     "evdr_l2norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
     "evdr_l2norm_fwd_split": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -56,7 +57,7 @@ class EvdrError(RuntimeError):
         self.code = code
 
 
-ABI_VERSION = 301                  # EVDR_VERSION_NUM of csrc/evdr_common.h these signatures belong to
+ABI_VERSION = 302                  # EVDR_VERSION_NUM of csrc/evdr_common.h these signatures belong to
 
 _lib: Optional[C.CDLL] = None
 

@@ -279,6 +279,20 @@ int evdr_maxsim_bwd_adamw_planes(const float* g, const float* Q, const uint8_t* 
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd_adamw launch");
 }
 
+int evdr_adamw_step(const float* grad, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, void* hip_stream) {
+    if (n < 0) return fail(EVDR_ERR_ARG, "negative size");
+    if (n == 0) return EVDR_OK;
+    if (!grad || !x || !exp_avg || !exp_avg_sq) return fail(EVDR_ERR_ARG, "evdr_adamw_step: null pointer");
+    if (((uintptr_t)grad | (uintptr_t)x | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
+        return fail(EVDR_ERR_ARG, "evdr_adamw_step: tensors must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)(step < 1 ? 1 : step));
+    const double bc2 = 1.0 - pow((double)beta2, (double)(step < 1 ? 1 : step));
+    hipError_t e = evdr_launch_adamw(grad, x, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrt(bc2),
+                                     (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "adamw launch");
+}
+
 int evdr_adamw_advance(void* adamw_state, float beta1, float beta2, void* hip_stream) {
     if (!adamw_state) return fail(EVDR_ERR_ARG, "evdr_adamw_advance: null state");
     hipError_t e = evdr_launch_adamw_advance(adamw_state, beta1, beta2, (hipStream_t)hip_stream);

@@ -49,6 +49,43 @@ __global__ void adamw_advance_kernel(void* state, float beta1, float beta2) {
     bc[1] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
 }
 
+// torch.optim.AdamW's update (amsgrad = False, maximize = False) of one fp32 tensor as ONE pure stream: g, x, exp_avg, exp_avg_sq
+// read once, x / exp_avg / exp_avg_sq written once (28 B per element; torch's default foreach form makes eight passes over the
+// tensor: 207 us against 60 for the 13.5 M student parameters of the training step).  Same expressions in the same order as
+// torch's single-tensor form: decay, lerp of the first moment, second moment, addcdiv with step_size = lr / bc1.
+// n4 = elements / 4; tail elements (n % 4) are handled by the first threads.
+__global__ void __launch_bounds__(256) adamw_kernel(const float* __restrict__ g, float* __restrict__ x, float* __restrict__ ea,
+                                                    float* __restrict__ es, int64_t n, float decay, float w1, float beta2,
+                                                    float w2, float step_size, float bc2_sqrt, float eps) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 av = reinterpret_cast<const f32x4*>(ea)[i];
+        f32x4 sv = reinterpret_cast<const f32x4*>(es)[i];
+        xv *= decay;
+        av = av + (gv - av) * w1;
+        sv = sv * beta2 + gv * gv * w2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[k] -= step_size * (av[k] / (sqrtf(sv[k]) / bc2_sqrt + eps));
+        reinterpret_cast<f32x4*>(x)[i] = xv;
+        reinterpret_cast<f32x4*>(ea)[i] = av;
+        reinterpret_cast<f32x4*>(es)[i] = sv;
+    }
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float gv = g[t];
+        float xv = x[t] * decay;
+        const float av = ea[t] + (gv - ea[t]) * w1;
+        const float sv = es[t] * beta2 + gv * gv * w2;
+        xv -= step_size * (av / (sqrtf(sv) / bc2_sqrt + eps));
+        x[t] = xv;
+        ea[t] = av;
+        es[t] = sv;
+    }
+}
+
 template <int BW_ROWS, int CHUNK, bool FUSED>
 __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __restrict__ g,
                                                                const float* __restrict__ Q,
@@ -595,6 +632,18 @@ hipError_t evdr_launch_maxsim_bwd_adamw(const float* g, const float* Q, const ui
                 state ? reinterpret_cast<const float*>(reinterpret_cast<const long long*>(state) + 1) : nullptr,
                 (_Float16*)next_planes, next_planes ? (_Float16*)next_planes + np * lp * EVDR_D : nullptr, next_amax, pageflags};
     return dispatch_bwd<true>(g, Q, qmask, pmask, argmax, nullptr, nq, lq, np, lp, ad, stream);
+}
+
+hipError_t evdr_launch_adamw(const float* g, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, double bc1, double bc2_sqrt, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const int64_t n4 = (n + 3) / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;                     // grid-stride: 16 workgroups per CU keep the stream full
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, x, exp_avg, exp_avg_sq, n,
+                       (float)(1.0 - (double)lr * (double)weight_decay), (float)(1.0 - (double)beta1), beta2,
+                       (float)(1.0 - (double)beta2), (float)((double)lr / bc1), (float)bc2_sqrt, eps);
+    return hipGetLastError();
 }
 
 hipError_t evdr_launch_adamw_advance(void* state, float beta1, float beta2, hipStream_t stream) {

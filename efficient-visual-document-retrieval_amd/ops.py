@@ -398,6 +398,23 @@ def maxsim_backward_adamw(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torc
         torch.autograd.graph.increment_version(t)
 
 
+def adamw_step(grad: torch.Tensor, x: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, lr: float,
+               betas: Tuple[float, float], eps: float, weight_decay: float, step: int) -> None:
+    """torch.optim.AdamW's update of ONE fp32 tensor in one pass (evdr_adamw_step), in place on x / exp_avg / exp_avg_sq;
+    `step` counts this update.  All four tensors dense fp32 of one shape on one device."""
+    dev = _require_cuda(grad, x, exp_avg, exp_avg_sq)
+    for t in (grad, x, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != x.shape:
+            raise RuntimeError("adamw_step: grad / x / exp_avg / exp_avg_sq must be contiguous fp32 tensors of one shape")
+    lib = L.load()
+    with L.on(dev):
+        L.check(lib.evdr_adamw_step(L.ptr(grad), L.ptr(x), L.ptr(exp_avg), L.ptr(exp_avg_sq), x.numel(), float(lr),
+                                    float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
+                                    L.current_stream_handle(dev)))
+    for t in (x, exp_avg, exp_avg_sq):
+        torch.autograd.graph.increment_version(t)
+
+
 def adamw_state(dev) -> torch.Tensor:
     """Zeroed device-side AdamW step counter {int64 step; float bc1; float bc2_sqrt} (16 bytes)."""
     return torch.zeros(2, dtype=torch.int64, device=dev)

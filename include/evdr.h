@@ -173,6 +173,12 @@ int evdr_maxsim_bwd_adamw_planes(const float* g, const float* Q, const uint8_t* 
  * zero-initialised.  evdr_adamw_advance does step += 1 and refreshes the bias corrections; evdr_maxsim_bwd_adamw with a
  * non-NULL state reads them from there and ignores its `step` argument. */
 int evdr_adamw_advance(void* adamw_state, float beta1, float beta2, void* hip_stream);
+/* The optimizer of A7 on its own (utils/utils.py:78-80 -> torch.optim.AdamW at torch's default betas / eps, amsgrad off), for
+ * callers that keep the reference's autograd step (loss.backward(); opt.step(), mainv2_iter_distill_infonce.py:290-291): one
+ * pass over grad, x, exp_avg, exp_avg_sq (n fp32 elements each, 16-byte aligned, dense), in place; `step` >= 1 is the count
+ * INCLUDING this update (bias corrections 1 - beta^step).  torch's default (foreach) form makes eight passes. */
+int evdr_adamw_step(const float* grad, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, void* hip_stream);
 
 /* ---- A4: l2_normalize (utils/preprocess_data.py:8-9) fused with the page mask, forward and backward -----------------
  * y[r,:] = m_r * x[r,:] / (||m_r * x[r,:]||_2 + eps), m_r = rowmask[r] != 0 (NULL = all ones); rows x 128 fp32.

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_and_error_string(lib):
     from evdr_amd import _lib
-    assert lib.evdr_version() == _lib.ABI_VERSION == 301
+    assert lib.evdr_version() == _lib.ABI_VERSION == 302
     assert isinstance(lib.evdr_last_error(), bytes)
 
 

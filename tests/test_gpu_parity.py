@@ -457,14 +457,17 @@ def test_a5_one_launch_form_equals_two_launch_form(dev, b, n):
 
 @pytest.mark.parametrize("tag", ["b4n8", "b32n128"])
 def test_a7_train_step(golden, dev, ER, tag):
-    """mainv2_iter_distill_infonce.py:269-292 call pattern with the drop-in functions + torch AdamW."""
+    """mainv2_iter_distill_infonce.py:269-292 call pattern with the drop-in functions, incl. the optimizer the scripts get from
+    utils.set_optimizer (utils/utils.py:78-80: AdamW -- here on the one-pass update kernel)."""
     from evdr_amd.criterion import infonce_distillation_loss
     from evdr_amd.utils.preprocess_data import l2_normalize
+    from evdr_amd.utils.utils import StreamAdamW, set_optimizer
     z = golden("a7_step_" + tag)
     Qb, qmb, Pt, pmt, Pbar0, pms, hp = [x.to(dev) if torch.is_tensor(x) else x for x in R.train_case(tag)]
     Pt_norm = l2_normalize(Pt * pmt.unsqueeze(-1)).detach()
     param = torch.nn.Parameter(Pbar0 * pms.unsqueeze(-1))
-    opt = torch.optim.AdamW([param], lr=hp["lr"], weight_decay=hp["wd"])
+    opt = set_optimizer("adamw", param, hp["lr"], hp["wd"])
+    assert isinstance(opt, StreamAdamW) and isinstance(opt, torch.optim.AdamW)
     Psb = l2_normalize(param * pms.unsqueeze(-1))
     with torch.no_grad():
         sc_t = ER.score_multi_vector_masked(Qb, Pt_norm, qmb, pmt, 64)
@@ -491,6 +494,50 @@ def test_a7_train_step(golden, dev, ER, tag):
         dpar = np.abs(param.detach()[::8, ::8, ::4].cpu().numpy() - z["param_sample"])
         assert (dpar > 1e-6).mean() < 1e-3 and dpar.max() < 2 * hp["lr"], ((dpar > 1e-6).mean(), dpar.max())
         np.testing.assert_allclose(param.detach().double().norm().item(), float(z["param_norm"]), rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(500, 206, 128), (7, 13, 128), (3, 5), (1,), (4099,)])
+def test_stream_adamw_equals_torch_adamw(dev, shape):
+    """StreamAdamW (evdr_adamw_step: one pass) against torch.optim.AdamW step after step: weight decay, bias corrections, zero
+    and tiny gradients, sizes that are not multiples of 4; the state keeps torch's layout, so state_dict round-trips into a plain
+    torch.optim.AdamW that continues identically."""
+    from evdr_amd.utils.utils import StreamAdamW
+    gen = torch.Generator().manual_seed(sum(shape))
+    x0 = torch.randn(shape, generator=gen)
+    a = torch.nn.Parameter(x0.clone().to(dev))
+    b = torch.nn.Parameter(x0.clone().to(dev))
+    oa = StreamAdamW([a], lr=1e-3, weight_decay=1e-2)
+    ob = torch.optim.AdamW([b], lr=1e-3, weight_decay=1e-2)
+    for i in range(12):
+        g = torch.randn(shape, generator=gen) * (10.0 ** -(i % 5))
+        if i == 3:
+            g.zero_()
+        if i == 4:
+            g.flatten()[:: 3] = 1e-9
+        a.grad, b.grad = g.clone().to(dev), g.clone().to(dev)
+        oa.step()
+        ob.step()
+        # first steps move a parameter by ~lr * g / (|g| + eps): one rounding of the update is ~1e-10; tiny gradients near eps are
+        # where the two forms may differ by an ulp of the quotient
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=0, atol=2e-7, err_msg=f"step {i}")
+    sa, sb = oa.state[a], ob.state[b]
+    assert float(sa["step"]) == float(sb["step"]) == 12.0
+    np.testing.assert_allclose(sa["exp_avg"].cpu().numpy(), sb["exp_avg"].cpu().numpy(), rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(sa["exp_avg_sq"].cpu().numpy(), sb["exp_avg_sq"].cpu().numpy(), rtol=1e-6, atol=1e-20)
+    c = torch.nn.Parameter(a.detach().clone())
+    oc = torch.optim.AdamW([c], lr=1e-3, weight_decay=1e-2)
+    oc.load_state_dict(oa.state_dict())
+    g = torch.randn(shape, generator=gen).to(dev)
+    a.grad, c.grad = g.clone(), g.clone()
+    oa.step()
+    oc.step()
+    np.testing.assert_allclose(a.detach().cpu().numpy(), c.detach().cpu().numpy(), rtol=0, atol=2e-7)
+    # a CPU parameter falls through to torch's own step (host-side plumbing; nothing of the scoring path is involved)
+    d = torch.nn.Parameter(x0.clone())
+    od = StreamAdamW([d], lr=1e-3, weight_decay=1e-2)
+    d.grad = torch.ones_like(d)
+    od.step()
+    assert torch.isfinite(d).all() and not torch.equal(d.detach(), x0)
 
 
 def test_a6_full_gradient_identical_inputs(dev, ER):
