@@ -517,9 +517,9 @@ def test_stream_adamw_equals_torch_adamw(dev, shape):
         a.grad, b.grad = g.clone().to(dev), g.clone().to(dev)
         oa.step()
         ob.step()
-        # first steps move a parameter by ~lr * g / (|g| + eps): one rounding of the update is ~1e-10; tiny gradients near eps are
-        # where the two forms may differ by an ulp of the quotient
-        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=0, atol=2e-7, err_msg=f"step {i}")
+        # the two forms round `x * decay - step_size * (m / denom)` in a different order (fused multiply-add or not): a parameter
+        # may differ by an ulp per step (1.4 % of the elements do on the first step), nothing more
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2.4e-7 * (i + 1), atol=2e-7, err_msg=f"step {i}")
     sa, sb = oa.state[a], ob.state[b]
     assert float(sa["step"]) == float(sb["step"]) == 12.0
     np.testing.assert_allclose(sa["exp_avg"].cpu().numpy(), sb["exp_avg"].cpu().numpy(), rtol=1e-6, atol=1e-12)
@@ -531,7 +531,7 @@ def test_stream_adamw_equals_torch_adamw(dev, shape):
     a.grad, c.grad = g.clone(), g.clone()
     oa.step()
     oc.step()
-    np.testing.assert_allclose(a.detach().cpu().numpy(), c.detach().cpu().numpy(), rtol=0, atol=2e-7)
+    np.testing.assert_allclose(a.detach().cpu().numpy(), c.detach().cpu().numpy(), rtol=2.4e-7, atol=2e-7)
     # a CPU parameter falls through to torch's own step (host-side plumbing; nothing of the scoring path is involved)
     d = torch.nn.Parameter(x0.clone())
     od = StreamAdamW([d], lr=1e-3, weight_decay=1e-2)
