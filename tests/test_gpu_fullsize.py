@@ -88,7 +88,12 @@ def test_config2_full_vidore_size_properties(dev):
     ma[:, ::2] = True
     sa = corpus.score(Q, ma)
     sb = corpus.score(Q, ~ma)
-    assert (sa + sb - s1).abs().max().item() < 2e-5
+    add = (sa + sb - s1).abs()
+    if add.max().item() >= 2e-5:       # seen ONCE (round 3, one box, 8.7e-3) and never reproduced in 450 k stress launches: say where
+        again = [(corpus.score(Q) != s1).sum().item(), (corpus.score(Q, ma) != sa).sum().item(), (corpus.score(Q, ~ma) != sb).sum().item()]
+        bad = (add >= 2e-5).nonzero()
+        raise AssertionError(f"token additivity: {len(bad)} entries off, max {add.max().item():.3e}, first (q, p) {bad[:8].tolist()}; "
+                             f"entries that differ when s1 / sa / sb are recomputed: {again}")
     # a random sample of pages against the oracle
     cols = torch.randperm(n)[:48]
     want = O.maxsim_masked(Q[:16].float().cpu(), P[cols.to(dev)].float().cpu(), torch.ones(16, LQ, dtype=torch.bool),
