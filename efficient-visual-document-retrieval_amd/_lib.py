@@ -13,7 +13,7 @@ EVDR_OK, EVDR_ERR_ARG, EVDR_ERR_SHAPE, EVDR_ERR_WORKSPACE, EVDR_ERR_HIP = 0, 1, 
 EVDR_F32, EVDR_BF16, EVDR_F16 = 0, 1, 2
 EVDR_TOPK_MAX = 128
 
-_i64, _i32, _f32, _sz, _vp = C.c_int64, C.c_int32, C.c_float, C.c_size_t, C.c_void_p
+_i64, _i32, _f32, _f64, _sz, _vp = C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_size_t, C.c_void_p
 
 # name -> (restype, argtypes); mirrors include/evdr.h one to one (tests check the export list against the header)
 SIGNATURES = {
@@ -29,11 +29,11 @@ SIGNATURES = {
     "evdr_maxsim_bwd_q_workspace": (_sz, [_i64, _i64, _i64, _i64]),
     "evdr_maxsim_bwd_q": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     "evdr_maxsim_bwd_adamw": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
-                                        _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp, _vp]),
+                                        _f64, _f64, _f64, _f64, _f64, _i64, _f32, _vp, _vp]),
     "evdr_maxsim_bwd_adamw_planes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
-                                               _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
-    "evdr_adamw_advance": (C.c_int, [_vp, _f32, _f32, _vp]),
-    "evdr_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _vp]),
+                                               _f64, _f64, _f64, _f64, _f64, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "evdr_adamw_advance": (C.c_int, [_vp, _f64, _f64, _vp]),
+    "evdr_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _vp]),
     "evdr_l2norm_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
     "evdr_l2norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
     "evdr_l2norm_fwd_split": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

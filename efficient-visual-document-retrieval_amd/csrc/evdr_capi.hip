@@ -250,7 +250,7 @@ int evdr_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, cons
 
 int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
                           float* x, float* exp_avg, float* exp_avg_sq, int64_t nq, int64_t lq, int64_t np, int64_t lp,
-                          int64_t d, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                          int64_t d, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
                           float l2_eps, const void* adamw_state_or_null, void* hip_stream) {
     return evdr_maxsim_bwd_adamw_planes(g, Q, qmask, pmask, argmax, x, exp_avg, exp_avg_sq, nq, lq, np, lp, d, lr, beta1, beta2,
                                         eps, weight_decay, step, l2_eps, adamw_state_or_null, nullptr, nullptr, nullptr,
@@ -259,8 +259,8 @@ int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, 
 
 int evdr_maxsim_bwd_adamw_planes(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                  const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq, int64_t nq, int64_t lq,
-                                 int64_t np, int64_t lp, int64_t d, float lr, float beta1, float beta2, float eps,
-                                 float weight_decay, int64_t step, float l2_eps, const void* adamw_state_or_null,
+                                 int64_t np, int64_t lp, int64_t d, double lr, double beta1, double beta2, double eps,
+                                 double weight_decay, int64_t step, float l2_eps, const void* adamw_state_or_null,
                                  void* next_planes_or_null, uint32_t* next_amax_or_null, uint32_t* pageflags_or_null,
                                  void* hip_stream) {
     if (int rc = check_common(nq, lq, np, lp)) return rc;
@@ -270,30 +270,30 @@ int evdr_maxsim_bwd_adamw_planes(const float* g, const float* Q, const uint8_t* 
     if (!x || !exp_avg || !exp_avg_sq) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_adamw: null parameter/state");
     if (nq > 0 && lq > 0 && (!g || !Q || !argmax)) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_adamw: null g/Q/argmax");
     if (next_planes_or_null && !next_amax_or_null) return fail(EVDR_ERR_ARG, "evdr_maxsim_bwd_adamw_planes: planes without their absmax word");
-    const double bc1 = 1.0 - pow((double)beta1, (double)(step < 1 ? 1 : step));
-    const double bc2 = 1.0 - pow((double)beta2, (double)(step < 1 ? 1 : step));
+    const double bc1 = 1.0 - pow(beta1, (double)(step < 1 ? 1 : step));
+    const double bc2 = 1.0 - pow(beta2, (double)(step < 1 ? 1 : step));
     hipError_t e = evdr_launch_maxsim_bwd_adamw(g, Q, qmask, pmask, argmax, x, exp_avg, exp_avg_sq, nq, lq, np, lp, lr, beta1,
-                                                beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), l2_eps,
+                                                beta2, eps, weight_decay, bc1, sqrt(bc2), l2_eps,
                                                 adamw_state_or_null, next_planes_or_null, next_amax_or_null,
                                                 pageflags_or_null, (hipStream_t)hip_stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "maxsim_bwd_adamw launch");
 }
 
-int evdr_adamw_step(const float* grad, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, int64_t step, void* hip_stream) {
+int evdr_adamw_step(const float* grad, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, int64_t step, void* hip_stream) {
     if (n < 0) return fail(EVDR_ERR_ARG, "negative size");
     if (n == 0) return EVDR_OK;
     if (!grad || !x || !exp_avg || !exp_avg_sq) return fail(EVDR_ERR_ARG, "evdr_adamw_step: null pointer");
     if (((uintptr_t)grad | (uintptr_t)x | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
         return fail(EVDR_ERR_ARG, "evdr_adamw_step: tensors must be 16-byte aligned");
-    const double bc1 = 1.0 - pow((double)beta1, (double)(step < 1 ? 1 : step));
-    const double bc2 = 1.0 - pow((double)beta2, (double)(step < 1 ? 1 : step));
+    const double bc1 = 1.0 - pow(beta1, (double)(step < 1 ? 1 : step));
+    const double bc2 = 1.0 - pow(beta2, (double)(step < 1 ? 1 : step));
     hipError_t e = evdr_launch_adamw(grad, x, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrt(bc2),
                                      (hipStream_t)hip_stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "adamw launch");
 }
 
-int evdr_adamw_advance(void* adamw_state, float beta1, float beta2, void* hip_stream) {
+int evdr_adamw_advance(void* adamw_state, double beta1, double beta2, void* hip_stream) {
     if (!adamw_state) return fail(EVDR_ERR_ARG, "evdr_adamw_advance: null state");
     hipError_t e = evdr_launch_adamw_advance(adamw_state, beta1, beta2, (hipStream_t)hip_stream);
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "adamw_advance launch");

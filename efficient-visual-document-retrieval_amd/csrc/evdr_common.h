@@ -6,7 +6,7 @@
 
 #include "../../include/evdr.h"
 
-#define EVDR_VERSION_NUM 302   /* 0.3.2: evdr_adamw_step (0.3.1: evdr_maxsim_bwd_adamw_planes; 0.3.0: debug hooks instead of environment switches) */
+#define EVDR_VERSION_NUM 302   /* 0.3.2: evdr_adamw_step, AdamW hyper-parameters as doubles (0.3.1: evdr_maxsim_bwd_adamw_planes; 0.3.0: debug hooks instead of environment switches) */
 
 #define EVDR_D 128              /* embedding width the kernels are specialised for */
 #define EVDR_TILE_PATCHES 32    /* patches per LDS tile (two 16-row MFMA halves) */
@@ -117,12 +117,12 @@ hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t*
                                   int64_t lp, hipStream_t stream);
 hipError_t evdr_launch_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                         const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq, int64_t nq,
-                                        int64_t lq, int64_t np, int64_t lp, float lr, float beta1, float beta2, float eps,
-                                        float weight_decay, float bc1, float bc2_sqrt, float eps_norm, const void* state,
+                                        int64_t lq, int64_t np, int64_t lp, double lr, double beta1, double beta2, double eps,
+                                        double weight_decay, double bc1, double bc2_sqrt, float eps_norm, const void* state,
                                         void* next_planes, uint32_t* next_amax, uint32_t* pageflags, hipStream_t stream);
-hipError_t evdr_launch_adamw_advance(void* state, float beta1, float beta2, hipStream_t stream);
-hipError_t evdr_launch_adamw(const float* g, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, double bc1, double bc2_sqrt, hipStream_t stream);
+hipError_t evdr_launch_adamw_advance(void* state, double beta1, double beta2, hipStream_t stream);
+hipError_t evdr_launch_adamw(const float* g, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, double bc1, double bc2_sqrt, hipStream_t stream);
 hipError_t evdr_launch_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint32_t* pageflags,
                                     const uint16_t* argmax, float* dQ, float* partials, int64_t nq, int64_t lq, int64_t np,
                                     int64_t lp, hipStream_t stream);

@@ -27,7 +27,9 @@ struct AdamArgs {
     float* x;            // (np, lp, 128) raw parameter, updated in place
     float* exp_avg;      // first moment
     float* exp_avg_sq;   // second moment
-    float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, eps_norm;
+    // hyper-parameters arrive as doubles (Python floats) and are combined in double on the host like torch does:
+    // decay = 1 - lr * weight_decay, w1 = 1 - beta1, w2 = 1 - beta2 (1 - float(0.999) would be off by 1.3e-5 relative)
+    float lr, decay, w1, beta2, w2, eps, bc1, bc2_sqrt, eps_norm;
     const float* bc_dev; // null, or {bc1, bc2_sqrt} in device memory (step counted on the device: HIP-graph replays)
     // null, or where the NEXT forward's operands go: l2_normalize(m * x_new) as the scorer's fp16 hi/lo planes (exactly what
     // l2norm_fwd_kernel<true> would produce from the updated x), the absmax word of the planes and the page flag words that
@@ -40,13 +42,13 @@ struct AdamArgs {
 
 // Device-resident step counter of an AdamW state: {int64 step; float bc1 = 1 - beta1^step; float bc2_sqrt}.  One thread; part
 // of the captured graph of a training step, so a replay needs no scalar from the host.
-__global__ void adamw_advance_kernel(void* state, float beta1, float beta2) {
+__global__ void adamw_advance_kernel(void* state, double beta1, double beta2) {
     long long* step = reinterpret_cast<long long*>(state);
     float* bc = reinterpret_cast<float*>(step + 1);
     const long long t = *step + 1;
     *step = t;
-    bc[0] = (float)(1.0 - pow((double)beta1, (double)t));
-    bc[1] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+    bc[0] = (float)(1.0 - pow(beta1, (double)t));
+    bc[1] = (float)sqrt(1.0 - pow(beta2, (double)t));
 }
 
 // torch.optim.AdamW's update (amsgrad = False, maximize = False) of one fp32 tensor as ONE pure stream: g, x, exp_avg, exp_avg_sq
@@ -280,16 +282,16 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
             // ---- AdamW (torch.optim.AdamW, amsgrad=False, maximize=False)
             f32x4 ea0 = in.ea0, ea1 = in.ea1;
             f32x4 es0 = in.es0, es1 = in.es1;
-            const float decay = 1.f - ad.lr * ad.weight_decay;
+            const float decay = ad.decay;
             const float bc1 = ad.bc_dev ? ad.bc_dev[0] : ad.bc1;
             const float bc2_sqrt = ad.bc_dev ? ad.bc_dev[1] : ad.bc2_sqrt;
             const float step_size = ad.lr / bc1;
             x0 *= decay;
             x1 *= decay;
-            ea0 = ea0 * ad.beta1 + d0 * (1.f - ad.beta1);
-            ea1 = ea1 * ad.beta1 + d1 * (1.f - ad.beta1);
-            es0 = es0 * ad.beta2 + d0 * d0 * (1.f - ad.beta2);
-            es1 = es1 * ad.beta2 + d1 * d1 * (1.f - ad.beta2);
+            ea0 = ea0 + (d0 - ea0) * ad.w1;                  // torch's lerp form of the first moment
+            ea1 = ea1 + (d1 - ea1) * ad.w1;
+            es0 = es0 * ad.beta2 + d0 * d0 * ad.w2;
+            es1 = es1 * ad.beta2 + d1 * d1 * ad.w2;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 x0[k] -= step_size * (ea0[k] / (sqrtf(es0[k]) / bc2_sqrt + ad.eps));
@@ -625,28 +627,29 @@ hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t*
 
 hipError_t evdr_launch_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                         const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq, int64_t nq,
-                                        int64_t lq, int64_t np, int64_t lp, float lr, float beta1, float beta2, float eps,
-                                        float weight_decay, float bc1, float bc2_sqrt, float eps_norm, const void* state,
+                                        int64_t lq, int64_t np, int64_t lp, double lr, double beta1, double beta2, double eps,
+                                        double weight_decay, double bc1, double bc2_sqrt, float eps_norm, const void* state,
                                         void* next_planes, uint32_t* next_amax, uint32_t* pageflags, hipStream_t stream) {
-    AdamArgs ad{x, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, eps_norm,
+    AdamArgs ad{x, exp_avg, exp_avg_sq, (float)lr, (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2,
+                (float)(1.0 - beta2), (float)eps, (float)bc1, (float)bc2_sqrt, eps_norm,
                 state ? reinterpret_cast<const float*>(reinterpret_cast<const long long*>(state) + 1) : nullptr,
                 (_Float16*)next_planes, next_planes ? (_Float16*)next_planes + np * lp * EVDR_D : nullptr, next_amax, pageflags};
     return dispatch_bwd<true>(g, Q, qmask, pmask, argmax, nullptr, nq, lq, np, lp, ad, stream);
 }
 
-hipError_t evdr_launch_adamw(const float* g, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, double bc1, double bc2_sqrt, hipStream_t stream) {
+hipError_t evdr_launch_adamw(const float* g, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, double bc1, double bc2_sqrt, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const int64_t n4 = (n + 3) / 4;
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;                     // grid-stride: 16 workgroups per CU keep the stream full
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, x, exp_avg, exp_avg_sq, n,
-                       (float)(1.0 - (double)lr * (double)weight_decay), (float)(1.0 - (double)beta1), beta2,
-                       (float)(1.0 - (double)beta2), (float)((double)lr / bc1), (float)bc2_sqrt, eps);
+                       (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)(lr / bc1), (float)bc2_sqrt, (float)eps);
     return hipGetLastError();
 }
 
-hipError_t evdr_launch_adamw_advance(void* state, float beta1, float beta2, hipStream_t stream) {
+hipError_t evdr_launch_adamw_advance(void* state, double beta1, double beta2, hipStream_t stream) {
     hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, stream, state, beta1, beta2);
     return hipGetLastError();
 }

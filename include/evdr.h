@@ -150,11 +150,14 @@ int evdr_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, cons
  * (1) the backward of  y = m x / (||m x|| + l2_eps)  (l2_normalize(Pbar * pmask), utils/preprocess_data.py:8-9) and
  * (2) torch.optim.AdamW's update (decoupled weight decay, bias correction with `step` = 1 for the first update)
  * in place on the raw parameter x (np,lp,128) and its moments exp_avg / exp_avg_sq (same shape, zero-initialised).
- * pmask doubles as the row mask m.  Result-identical to backward() + AdamW.step() of the reference's step. */
+ * pmask doubles as the row mask m.  Result-identical to backward() + AdamW.step() of the reference's step.
+ * lr / betas / eps / weight_decay are DOUBLES, as Python hands them to torch: the derived constants (1 - lr * weight_decay,
+ * 1 - beta, lr / (1 - beta1^step), ...) are formed in double on the host like torch forms them and only then rounded to fp32
+ * (1 - float(0.999) would be off by 1.3e-5 relative). */
 int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                           const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq,
                           int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d,
-                          float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                          double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
                           float l2_eps, const void* adamw_state_or_null, void* hip_stream);
 /* The same launch, also emitting the NEXT forward's operands: l2_normalize(m * x_new) of the updated parameter as the fp16
  * hi/lo planes evdr_l2norm_fwd_split would produce from it (next_planes: 2 x np x lp x 128 fp16, next_amax: their absmax
@@ -164,7 +167,7 @@ int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, 
 int evdr_maxsim_bwd_adamw_planes(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                  const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq,
                                  int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d,
-                                 float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                 double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
                                  float l2_eps, const void* adamw_state_or_null,
                                  void* next_planes_or_null, uint32_t* next_amax_or_null, uint32_t* pageflags_or_null,
                                  void* hip_stream);
@@ -172,13 +175,13 @@ int evdr_maxsim_bwd_adamw_planes(const float* g, const float* Q, const uint8_t* 
  * replayed without a scalar from the host: adamw_state = 16 bytes of device memory {int64 step; float bc1; float bc2_sqrt},
  * zero-initialised.  evdr_adamw_advance does step += 1 and refreshes the bias corrections; evdr_maxsim_bwd_adamw with a
  * non-NULL state reads them from there and ignores its `step` argument. */
-int evdr_adamw_advance(void* adamw_state, float beta1, float beta2, void* hip_stream);
+int evdr_adamw_advance(void* adamw_state, double beta1, double beta2, void* hip_stream);
 /* The optimizer of A7 on its own (utils/utils.py:78-80 -> torch.optim.AdamW at torch's default betas / eps, amsgrad off), for
  * callers that keep the reference's autograd step (loss.backward(); opt.step(), mainv2_iter_distill_infonce.py:290-291): one
  * pass over grad, x, exp_avg, exp_avg_sq (n fp32 elements each, 16-byte aligned, dense), in place; `step` >= 1 is the count
  * INCLUDING this update (bias corrections 1 - beta^step).  torch's default (foreach) form makes eight passes. */
-int evdr_adamw_step(const float* grad, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, int64_t step, void* hip_stream);
+int evdr_adamw_step(const float* grad, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, int64_t step, void* hip_stream);
 
 /* ---- A4: l2_normalize (utils/preprocess_data.py:8-9) fused with the page mask, forward and backward -----------------
  * y[r,:] = m_r * x[r,:] / (||m_r * x[r,:]||_2 + eps), m_r = rowmask[r] != 0 (NULL = all ones); rows x 128 fp32.
