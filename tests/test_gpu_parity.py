@@ -527,7 +527,8 @@ def test_stream_adamw_equals_torch_adamw(dev, shape):
     np.testing.assert_allclose(sa["exp_avg_sq"].cpu().numpy(), sb["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=1e-12)
     c = torch.nn.Parameter(a.detach().clone())
     oc = torch.optim.AdamW([c], lr=1e-3, weight_decay=1e-2)
-    oc.load_state_dict(oa.state_dict())
+    import copy
+    oc.load_state_dict(copy.deepcopy(oa.state_dict()))              # load_state_dict keeps same-device tensors by reference
     g = torch.randn(shape, generator=gen).to(dev)
     a.grad, c.grad = g.clone(), g.clone()
     oa.step()
