@@ -1,14 +1,18 @@
 """Fuzz of the backward gather (evdr_maxsim_bwd) and of the fused update (evdr_maxsim_bwd_adamw_planes) against plain torch on the
 GPU: random page counts / lengths (both sides of the 128-row slab and of the 1024-pair chunk), masks, hot rows.
-usage: python scratch/fuzz_bwd.py <first_seed> <count>"""
+usage: python scratch/fuzz_bwd.py <first_seed> <count> [long]     (long, round 3: page lengths 1030 ... 65535, few pages)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); import evdr_amd
 from evdr_amd import ops
 dev = torch.device("cuda:0"); s0, n = int(sys.argv[1]), int(sys.argv[2]); bad = 0
+LONG = len(sys.argv) > 3 and sys.argv[3] == "long"
 for seed in range(s0, s0 + n):
     g = torch.Generator().manual_seed(seed)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
     npg, lp, nq, lq = ri(1, 9), [1, 7, 40, 127, 128, 129, 206, 300, 513][ri(0, 8)], ri(1, 70), [1, 5, 32, 33][ri(0, 3)]
+    if LONG:
+        lp = [1030, 2049, 4100, 8200, 20000, 32769, 65535][seed % 7]
+        npg = ri(1, 3 if lp > 9000 else 6)
     Q = torch.randn(nq, lq, 128, generator=g).to(dev)
     gr = (torch.randn(nq, npg, generator=g) * (0.0 if seed % 11 == 0 else 1.0)).to(dev)
     pm = (torch.rand(npg, lp, generator=g) > [0.0, 0.3, 0.9][ri(0, 2)]); qm = torch.rand(nq, lq, generator=g) > 0.25
