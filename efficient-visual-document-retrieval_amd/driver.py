@@ -106,7 +106,7 @@ def eval_index(evaluator: CustomRetrievalEvaluator, relevant_docs, docidx_2_doci
 @torch.no_grad()
 def eval_retrieval(evaluator: CustomRetrievalEvaluator, Q_test_norm, qmask_test, Pbar_param, pmask_student,
                    relevant_docs_test, docidx_2_docid_test, qsidx_2_query_test, chunk_p: int = 64, k: int = 100,
-                   shard_sizes=None, timing: Optional[Dict[str, float]] = None):
+                   shard_sizes=None, timing: Optional[Dict[str, float]] = None, keep: Optional[Dict[str, Any]] = None):
     """Retrieval metrics of the current student pages + "latency" (ms per query, synchronised).  With `shard_sizes`
     (page-sharded run) Pbar_param / pmask_student are this rank's pages and the score columns are all-gathered: every rank
     ends up with the same full score matrix and the same metrics.
@@ -115,6 +115,9 @@ def eval_retrieval(evaluator: CustomRetrievalEvaluator, Q_test_norm, qmask_test,
     (nq, 2k + 1) words back and `evaluate_topk` turns them into the metric tables with array operations -- no per-pair
     `.item()` (mainv2_iter_distill_infonce.py:311-317) and no per-query dict.  The numbers equal
     `compute_mteb_metrics(relevant_docs, results_from_topk(...))` bit for bit (tests/test_host_logic.py).
+    `keep` (optional dict) receives the full (nq, N) student score matrix of this evaluation ("scores"): `evaluation_loss`
+    right after it needs exactly these numbers (the reference scores the test queries three times per evaluation,
+    mainv2_iter_distill_infonce.py:308,338,340).
     `timing` (optional dict) receives the split of the call: device_ms (score + top-k, by HIP events), d2h_ms (candidate
     counts of the tie rule + the one copy of the candidates), host_ms (index lookup + metric tables), total_ms (the whole
     call, the normalisation of the pages included)."""
@@ -138,6 +141,8 @@ def eval_retrieval(evaluator: CustomRetrievalEvaluator, Q_test_norm, qmask_test,
         t_dev = time.perf_counter()
         ts, ti, tied = ops.topk_with_ties(scores, kk, to_host=True, have=(ts_d, ti_d))
     t1 = time.perf_counter()
+    if keep is not None:
+        keep["scores"] = scores
     latency_ms = (t1 - t0) * 1000 / max(Q_test_norm.shape[0], 1)
     nq, n = scores.shape
     index = eval_index(evaluator, relevant_docs_test, docidx_2_docid_test, qsidx_2_query_test, nq, n)
@@ -155,16 +160,28 @@ def eval_retrieval(evaluator: CustomRetrievalEvaluator, Q_test_norm, qmask_test,
 
 @torch.no_grad()
 def evaluation_loss(Q_test_norm, qmask_test, teacher, pmask_teacher, Pbar_param, pmask_student, temp: float,
-                    chunk_p: int = 64, shard_sizes=None) -> float:
-    """InfoNCE-distillation loss on the test queries (mainv2_iter_distill_infonce.py:324-344)."""
-    Psb = l2_normalize(Pbar_param * pmask_student.unsqueeze(-1))
-    if isinstance(teacher, TeacherScorer):
-        sc_t = teacher.scores(Q_test_norm, qmask_test)
-    else:
-        sc_t = score_multi_vector_masked(Q_test_norm, teacher, qmask_test, pmask_teacher, chunk_p=chunk_p)
-    sc_s = score_multi_vector_masked(Q_test_norm, Psb, qmask_test, pmask_student, chunk_p=chunk_p)
-    if shard_sizes is not None:
-        sc_t, sc_s = gather_columns(sc_t, tuple(shard_sizes)), gather_columns(sc_s, tuple(shard_sizes))
+                    chunk_p: int = 64, shard_sizes=None, sc_s: Optional[torch.Tensor] = None,
+                    teacher_cache: Optional[Dict[str, Any]] = None) -> float:
+    """InfoNCE-distillation loss on the test queries (mainv2_iter_distill_infonce.py:324-344).
+    `sc_s`: the full (nq, N) student scores of the current pages when the caller has them already (`eval_retrieval(keep=...)`
+    of the same pages: the same kernel on the same inputs).  `teacher_cache` (a dict the caller keeps per dataset): the teacher's
+    scores of the test queries are computed on the first evaluation and reused -- teacher and test queries never change
+    (the reference recomputes both matrices on every evaluation; same numbers)."""
+    sc_t = teacher_cache.get("sc_t") if teacher_cache is not None else None
+    if sc_t is None:
+        if isinstance(teacher, TeacherScorer):
+            sc_t = teacher.scores(Q_test_norm, qmask_test)
+        else:
+            sc_t = score_multi_vector_masked(Q_test_norm, teacher, qmask_test, pmask_teacher, chunk_p=chunk_p)
+        if shard_sizes is not None:
+            sc_t = gather_columns(sc_t, tuple(shard_sizes))
+        if teacher_cache is not None:
+            teacher_cache["sc_t"] = sc_t
+    if sc_s is None:
+        Psb = l2_normalize(Pbar_param * pmask_student.unsqueeze(-1))
+        sc_s = score_multi_vector_masked(Q_test_norm, Psb, qmask_test, pmask_student, chunk_p=chunk_p)
+        if shard_sizes is not None:
+            sc_s = gather_columns(sc_s, tuple(shard_sizes))
     return float(infonce_distillation_loss(sc_s, sc_t, temperature=temp).item())
 
 
@@ -299,6 +316,7 @@ def run(args) -> None:
                  "peak_bytes_after_teacher_load": int(torch.cuda.max_memory_allocated(device))}
         LOAD_STATS.append(stats)
         teacher = TeacherScorer(P_t_norm, pmask_t, cache_size=n_train if args.cache_teacher_scores else 0)
+        test_teacher_scores: Dict[str, Any] = {}              # the teacher's scores of the test queries: constant over the run
         del P_t_raw
         steps_per_epoch = (n_train + args.q_batch - 1) // args.q_batch
         eval_every = max(int(args.eval_every if args.eval_every and args.eval_every > 0 else steps_per_epoch), 1)
@@ -346,8 +364,11 @@ def run(args) -> None:
                            shard_sizes=shard_sizes)
             el_args = dict(Q_test_norm=Q_test, qmask_test=qmask_test, teacher=teacher, pmask_teacher=pmask_t,
                            Pbar_param=Pbar_param, pmask_student=pmask_s, temp=args.temp, shard_sizes=shard_sizes)
-            metrics = eval_retrieval(**ev_args)
-            log_eval(logger, tb, dataset=dataset, mf=mf, step=0, metrics=metrics, loss=evaluation_loss(**el_args))
+            # one student pass per evaluation (shared by the ranking and the loss) and one teacher pass per dataset and mf
+            kept: Dict[str, Any] = {}
+            el_args["teacher_cache"] = test_teacher_scores
+            metrics = eval_retrieval(**ev_args, keep=kept)
+            log_eval(logger, tb, dataset=dataset, mf=mf, step=0, metrics=metrics, loss=evaluation_loss(**el_args, sc_s=kept.pop("scores")))
             log_json(logger, {"dataset": dataset, "mf": mf, "step": 0, "note": "init Pbar before training"})
             best_r1, _ = update_best(None, metrics, 0, "r1")
             best_nd5, _ = update_best(None, metrics, 0, "nd5")
@@ -412,8 +433,9 @@ def run(args) -> None:
                     log_json(logger, {"dataset": dataset, "mf": mf, "step": step, "train/loss": float(loss_val),
                                       "train/avg_loss": float(loss_sum / max(loss_cnt, 1)), "time_sec": float(time.time() - t0)})
                 if step % eval_every == 0 or step == args.max_steps:
-                    metrics = eval_retrieval(**ev_args)
-                    log_eval(logger, tb, dataset=dataset, mf=mf, step=step, metrics=metrics, loss=evaluation_loss(**el_args))
+                    metrics = eval_retrieval(**ev_args, keep=kept)
+                    log_eval(logger, tb, dataset=dataset, mf=mf, step=step, metrics=metrics,
+                             loss=evaluation_loss(**el_args, sc_s=kept.pop("scores")))
                     last = metrics
                     best_r1, upd_r1 = update_best(best_r1, metrics, step, "r1")
                     best_nd5, upd_nd5 = update_best(best_nd5, metrics, step, "nd5")

@@ -249,6 +249,29 @@ def test_graphed_step_equals_eager_fused_step(golden, with_teacher):
     assert student.steps == eager.steps == 4 and int(step.state[0].item()) == 4
 
 
+def test_evaluation_shares_one_student_pass_and_one_teacher_pass(golden):
+    """driver.run scores the test queries once per evaluation (ranking and loss share the matrix) and the teacher once per dataset:
+    `evaluation_loss(sc_s=<eval_retrieval's scores>, teacher_cache=...)` is the number the stand-alone call computes (the reference
+    makes three passes per evaluation, mainv2_iter_distill_infonce.py:308,338,340)."""
+    import evdr_amd  # noqa: F401
+    import golden_recipes as R
+    from evdr_amd import driver
+    from evdr_amd.evaluator.retrieval import CustomRetrievalEvaluator
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    dev = torch.device("cuda:0")
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = [x.to(dev) if torch.is_tensor(x) else x for x in R.train_case("b32n128")]
+    teacher = driver.TeacherScorer(l2_normalize(Pt * pmt.unsqueeze(-1)), pmt)
+    n = Pt.shape[0]
+    docmap = {str(j): f"d{j}" for j in range(n)}
+    rel = {str(i): {docmap[str(i % n)]: 1} for i in range(Qb.shape[0])}
+    kept, cache = {}, {}
+    driver.eval_retrieval(CustomRetrievalEvaluator(), Qb, qmb, Pbar0, pms, rel, docmap, None, keep=kept)
+    plain = driver.evaluation_loss(Qb, qmb, teacher, pmt, Pbar0, pms, hp["temp"])
+    shared = driver.evaluation_loss(Qb, qmb, teacher, pmt, Pbar0, pms, hp["temp"], sc_s=kept["scores"], teacher_cache=cache)
+    again = driver.evaluation_loss(Qb, qmb, teacher, pmt, Pbar0, pms, hp["temp"], sc_s=kept["scores"], teacher_cache=cache)
+    assert plain == shared == again and "sc_t" in cache
+
+
 def test_fused_step_with_the_student_forward_on_a_second_stream(golden):
     """fused_train_one_step(overlap=True): the student forward is issued on a side stream beside the teacher forward; same
     losses and parameters as the one-stream step, step after step (stream hand-over of planes, scores and argmax)."""
