@@ -20,3 +20,27 @@ def test_cabi_from_plain_cpp(tmp_path):
                     "-L", libdir, "-levdr", f"-Wl,-rpath,{libdir}", "-o", exe], check=True, timeout=300)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "cabi_smoke OK" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_the_ctypes_stub_printed_in_integration_md_runs():
+    """INTEGRATION.md §2 shows the reference-side binding a maintainer would add (a ctypes stub around evdr_maxsim_fwd).  The block
+    is taken out of the document, pointed at the built library and executed: it must score like the oracle (no doc rot)."""
+    import re
+    import numpy as np
+    import torch
+    from oracle import maxsim_oracle as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "def maxsim_fwd(Q, P, qmask, pmask)" in b)
+    lib = os.path.join(root, "efficient-visual-document-retrieval_amd", "libevdr.so")
+    ns = {}
+    exec(compile(stub.replace("/path/to/libevdr.so", lib), "INTEGRATION.md:stub", "exec"), ns)
+    g = torch.Generator().manual_seed(21)
+    Q = torch.nn.functional.normalize(torch.randn(5, 12, 128, generator=g), dim=-1)
+    P = torch.nn.functional.normalize(torch.randn(9, 70, 128, generator=g), dim=-1)
+    qm = torch.rand(5, 12, generator=g) > 0.2
+    pm = torch.rand(9, 70, generator=g) > 0.2
+    pm[2] = False
+    got = ns["maxsim_fwd"](Q.cuda(), P.cuda(), qm.cuda(), pm.cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), O.maxsim_masked(Q, P, qm, pm).numpy(), atol=1e-4, rtol=0)
