@@ -382,7 +382,15 @@ def main():
                 "max_over_ranks": {n: float(v) for n, v in zip(names[:keep], worst[:keep])},
                 "note": "separate instrumented passes after the timed region (score and top-k as two calls; the timed step "
                         "issues them through one C-ABI call), mean of %d" % reps}
-    phases = phase_breakdown()
+    # everything after the timed region is evidence around the headline number: a failure there is recorded in the line, it
+    # must not cost the line itself (the first N > 1 run happens where nobody can re-run it)
+    def guarded(what, fn):
+        try:
+            return fn()
+        except Exception as e:                              # noqa: BLE001
+            print(f"bench.py: {what} failed: {type(e).__name__}: {e}", file=sys.stderr)
+            return {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+    phases = guarded("phase breakdown", phase_breakdown)
 
     # ---- roofline of the dominant kernel: HIP events around the MaxSim launch on its own stream
     out = torch.empty((args.queries, corpus.n_pages), dtype=torch.float32, device=dev)
@@ -443,7 +451,8 @@ def main():
                 "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
                 "algorithmic_bytes_per_launch": corpus.n_pages * LP * D * 2,
                 "mfma_tflops": nq_small * corpus.n_pages * FLOP_PER_PAIR / (ms * 1e-3) / 1e12}
-    roofline["other_regimes"] = [stream_regime(1), stream_regime(8)] if (args.queries >= 8 and not args.no_other_regimes) else []
+    roofline["other_regimes"] = guarded("other regimes", lambda: [stream_regime(1), stream_regime(8)]) \
+        if (args.queries >= 8 and not args.no_other_regimes) else []
 
     # ---- quality on the planted queries (rank 0; uses the merged top-k of the last step)
     ndcg5 = None
@@ -455,12 +464,15 @@ def main():
         ndcg5 = CustomRetrievalEvaluator().compute_mteb_metrics(qrels, res)["NDCG"]["NDCG@5"]
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = min(2048, corpus.n_pages)
-            cpu_base, s_cpu = cpu_baseline_leg(shard_pages[:n_cpu], Q)
-            dmax = (out[:32, :n_cpu].cpu() - s_cpu).abs().max().item()      # same inputs: the oracle as checker
-            cpu_base["max_abs_diff_vs_gpu"] = dmax
+            def cpu_leg():
+                base, s_cpu = cpu_baseline_leg(shard_pages[:n_cpu], Q)
+                base["max_abs_diff_vs_gpu"] = (out[:32, :n_cpu].cpu() - s_cpu).abs().max().item()   # same inputs: the oracle as checker
+                return base
+            cpu_base = guarded("cpu baseline", cpu_leg)
         train_step = eval_rec = None
         if world == 1 and not args.no_extras:
-            train_step, eval_rec = extras(dev, shard_pages, args)
+            both = guarded("train_step / eval records", lambda: extras(dev, shard_pages, args))
+            train_step, eval_rec = both if isinstance(both, tuple) else (both, both)
         line = {
             "metric": "query-page pairs scored/sec", "value": value, "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
