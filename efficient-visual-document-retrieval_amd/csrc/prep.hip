@@ -62,8 +62,7 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
                                                      const uint8_t* __restrict__ rowmask, int64_t rows_per_page,
                                                      uint32_t* __restrict__ pageflags) {
     uint32_t m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    auto fold = [&](const f32x4& v, int64_t i) {
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -75,7 +74,19 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
             const int64_t row = (i * 4) / EVDR_D;
             if (rowmask == nullptr || rowmask[row] != 0) atomicOr(&pageflags[row / rows_per_page], 8u);
         }
+    };
+    // four 16-B loads in flight per thread: with one, a 50-MB tensor took 21-23 us (2.3 TB/s, latency-bound: the grid
+    // covers 4 MB per sweep); rocprofv3 of the reference's call pattern, profiles/r03_callpattern_kernel_stats.csv
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (i + u * stride) * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fold(v[u], i + u * stride);
     }
+    for (; i < n4; i += stride) fold(*reinterpret_cast<const f32x4*>(x + i * 4), i);
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
     __shared__ uint32_t wmax[4];
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
