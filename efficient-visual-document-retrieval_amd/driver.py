@@ -209,6 +209,13 @@ def save_best_npz(*, out_dir: Path, fname: str, dataset: str, mf: int, step: int
               "latency": float(metrics["latency"]), "loss": "infonce_distillation_loss", "temp": args.temp, "lr": args.lr})
 
 
+def summary_record(last_metrics, best_r1, best_nd5) -> Dict[str, Any]:
+    """The last line of a run's train.log: what the reference's summary_results.py looks for (`"summary/best_ndcg5"` with
+    `NDCG@5` / `Recall@1`, summary_results.py:35,68-87; emitted by the reference at mainv2_iter_distill_infonce.py:254-259)."""
+    return {"summary/latency": float(last_metrics.get("latency", 0.0)), "summary/best_recall": best_r1,
+            "summary/best_ndcg5": best_nd5, "note": "training finished"}
+
+
 def log_eval(logger, tb, *, dataset: str, mf: int, step: int, metrics, loss: float):
     if tb is not None:
         tb.add_scalar("eval/Recall@1", float(metrics["Recall"]["Recall@1"]), step)
@@ -452,8 +459,7 @@ def run(args) -> None:
                                 save_best_npz(out_dir=out_dir, fname=fname, dataset=dataset, mf=mf, step=step, best=best,
                                               metrics=metrics, Pbar_param=P_all, pmask_student=pm_all, docid_tr=docid_tr,
                                               doc_attn_in=attn_in, doc_img_in=img_in, args=args)
-            log_json(logger, {"summary/latency": float(last.get("latency", 0.0)), "summary/best_recall": best_r1,
-                              "summary/best_ndcg5": best_nd5, "note": "training finished"})
+            log_json(logger, summary_record(last, best_r1, best_nd5))
             if rank == 0:
                 print(f"[done] {dataset} mf{mf} -> {out_dir}")
             if tb is not None:
