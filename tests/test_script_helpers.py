@@ -1,0 +1,39 @@
+"""driver.update_best / driver.evaluation_loss against what the reference's own mainv2_iter_distill_infonce.update_best (:373-392)
+and evaluation_loss (:324-344) returned (tests/golden/script_helpers.json, made by tests/golden/make_golden_script_helpers.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_recipes as R
+import script_helper_recipe as H
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "script_helpers.json")))
+
+
+@pytest.mark.parametrize("rec", GOLD["update_best"], ids=[r["kind"] for r in GOLD["update_best"]])
+def test_update_best_follows_the_reference(rec):
+    import evdr_amd  # noqa: F401
+    from evdr_amd import driver
+    best = None
+    for (step, r1, nd5), want in zip(H.EVALS, rec["trace"]):
+        best, upd = driver.update_best(best, {"Recall": {"Recall@1": r1}, "NDCG": {"NDCG@5": nd5}}, step, rec["kind"])
+        assert upd == want["updated"] and best == want["best"], (step, rec["kind"])
+
+
+@pytest.mark.gpu
+def test_evaluation_loss_matches_the_reference():
+    import evdr_amd  # noqa: F401
+    from evdr_amd import driver
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    dev = torch.device("cuda:0")
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = [x.to(dev) if torch.is_tensor(x) else x for x in R.v3_case()]
+    Ptn = l2_normalize(Pt * pmt.unsqueeze(-1))
+    param = Pbar0 * pms.unsqueeze(-1)
+    for temp, want in GOLD["evaluation_loss"].items():
+        got = driver.evaluation_loss(Qb, qmb, Ptn, pmt, param, pms, temp=float(temp))                       # the reference's signature
+        np.testing.assert_allclose(got, want, rtol=1e-5)
+        res = driver.evaluation_loss(Qb, qmb, driver.TeacherScorer(Ptn, pmt), pmt, param, pms, temp=float(temp))   # resident teacher
+        np.testing.assert_allclose(res, want, rtol=1e-5)
