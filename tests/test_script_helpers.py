@@ -37,3 +37,22 @@ def test_evaluation_loss_matches_the_reference():
         np.testing.assert_allclose(got, want, rtol=1e-5)
         res = driver.evaluation_loss(Qb, qmb, driver.TeacherScorer(Ptn, pmt), pmt, param, pms, temp=float(temp))   # resident teacher
         np.testing.assert_allclose(res, want, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_eval_retrieval_matches_the_reference_function():
+    """The reference's eval_retrieval (its own dict construction over ALL pairs, query keys from qsidx_2_query, docids from
+    docidx_2_docid) was run on the CPU with this repo's metric object plugged in (tests/golden/make_golden_eval.py); the device
+    path here -- top-100, tie-rule counts, one copy, array metric tables -- must return the same tables.  Relevant pages are at
+    least 4e-5 away from their neighbours in score (stored with the fixture); device and host scores differ by ~3e-6."""
+    import evdr_amd  # noqa: F401
+    import eval_recipe as E
+    from evdr_amd import driver
+    from evdr_amd.evaluator.retrieval import CustomRetrievalEvaluator
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval_retrieval.json")))
+    assert gold["min_gap_around_relevant_pages"] > 2e-5
+    dev = torch.device("cuda:0")
+    Qb, qmb, Pbar0, pms, rel, docmap, names = E.eval_case()
+    got = driver.eval_retrieval(CustomRetrievalEvaluator(), Qb.to(dev), qmb.to(dev), Pbar0.to(dev), pms.to(dev), rel, docmap, names)
+    assert got.pop("latency") > 0
+    assert got == gold["metrics"]
