@@ -35,13 +35,19 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, experiment: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, experiment: bool = False, sentinel: bool = False,
+          ring_fault: bool = False) -> str:
     """Compile every HIP source for gfx950 and link libevdr.so; returns its path.  experiment=True builds
     libevdr_exp.so with -DEVDR_EXPERIMENT instead (the stamped diagnostic kernel instances used by scratch/; never
-    loaded by the package)."""
-    obj_dir = OBJ_DIR + ("_exp" if experiment else "")
-    lib_path = LIB_PATH.replace("libevdr.so", "libevdr_exp.so") if experiment else LIB_PATH
-    flags = FLAGS + (["-DEVDR_EXPERIMENT"] if experiment else [])
+    loaded by the package).  sentinel=True builds libevdr_sentinel.so with -DEVDR_SENTINEL: the same kernels with every
+    LDS-DMA piece poisoning its destination first (csrc/maxsim_device.h), loaded only by tests/test_gpu_sentinel.py.
+    ring_fault=True (scratch/sentinel_control.py only) removes the ring hand-over's vmcnt wait: libevdr[_sentinel]_fault.so."""
+    suffix = "_exp" if experiment else ("_sentinel" if sentinel else "")
+    suffix += "_fault" if ring_fault else ""
+    obj_dir = OBJ_DIR + suffix
+    lib_path = LIB_PATH.replace("libevdr.so", f"libevdr{suffix}.so")
+    flags = FLAGS + (["-DEVDR_EXPERIMENT"] if experiment else []) + (["-DEVDR_SENTINEL"] if sentinel else []) + (
+        ["-DEVDR_RING_FAULT"] if ring_fault else [])
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
@@ -76,4 +82,5 @@ def build(force: bool = False, verbose: bool = True, experiment: bool = False) -
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, experiment="--experiment" in sys.argv)
+    build(force="--force" in sys.argv, experiment="--experiment" in sys.argv, sentinel="--sentinel" in sys.argv,
+          ring_fault="--ring-fault" in sys.argv)

@@ -9,11 +9,31 @@ constexpr int kTileBytes = EVDR_TILE_PATCHES * EVDR_D * 2;        // 8 KiB: one 
 
 __device__ __forceinline__ float neg_inf() { return -__builtin_inff(); }
 
+// ---- sentinel build (-DEVDR_SENTINEL, libevdr_sentinel.so: tests/test_gpu_sentinel.py; never the product library) ----
+// Every LDS-DMA piece first POISONS the 1 KiB it is about to fill (0x7B7B in every 16-bit element: 1.3e36 as bf16, 61 280
+// as fp16) and retires that write before the DMA is issued.  A ds_read that gets at a piece before its data has landed
+// (RAW), or a wave still reading a ring slot's previous tenant when the next refill starts (WAR), then sees the poison in
+// all 128 dims of the affected rows -- an astronomically wrong score on EVERY affected token -- instead of the old bytes
+// of a neighbouring tile, which change a score only when they happen to hold a token's best patch (~0.4 % per piece).
+#ifdef EVDR_SENTINEL
+__device__ __forceinline__ void sentinel_fill(uint32_t lds_base) {
+    // two VGPRs (address, pattern): the kernels that sit at 256 registers have no room for a 128-bit store operand
+    const uint32_t a = lds_base + (threadIdx.x & 63u) * 16u;
+    const uint32_t v = 0x7B7B7B7Bu;
+    asm volatile("ds_write2_b32 %0, %1, %1 offset1:1\n\tds_write2_b32 %0, %1, %1 offset0:2 offset1:3\n\ts_waitcnt lgkmcnt(0)"
+                 ::"v"(a), "v"(v) : "memory");
+}
+#else
+__device__ __forceinline__ void sentinel_fill(uint32_t) {}
+#endif
+
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [lds_base, lds_base + 1 KiB), lane-linear.
 // Issued as inline asm on purpose: hipcc does not see it, so (a) it cannot put a vmcnt(0) in front of the ds_reads of
 // the ring (it treats a builtin LDS-DMA as an LDS store that may alias them) and (b) the ring's completion is counted
-// by hand with wait_vmcnt<N>().  M0 is written and restored inside the statement (cdna_hip_programming.md §5.7).
+// by hand (ring_barrier<N>() below).  M0 is written and restored inside the statement (cdna_hip_programming.md §5.7); the
+// s_nop between the M0 write and the load is the SALU-writes-M0 -> LDS-DMA wait state.
 __device__ __forceinline__ void lds_dma_16B(const void* gsrc, uint32_t lds_base) {
+    sentinel_fill(lds_base);
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -30,6 +50,7 @@ __device__ __forceinline__ void lds_dma_16B(const void* gsrc, uint32_t lds_base)
 // piece instead of a 64-bit per-lane pointer (the staged kernel issues pieces in the middle of its MFMA block, where
 // VGPRs are scarce).  s_nop 4 covers a base that was just produced by a VALU->SGPR move (§5.7 item 2).
 __device__ __forceinline__ void lds_dma_16B_sbase(const void* sbase, uint32_t voff, uint32_t lds_base) {
+    sentinel_fill(lds_base);
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -46,6 +67,7 @@ __device__ __forceinline__ void lds_dma_16B_sbase(const void* sbase, uint32_t vo
 // single query group: 1-32 queries): they need no place in L2 / Infinity Cache, and the stream lands sooner
 // (MI355X_MICROARCH.md "nt-weights": issued -> landed -18 %).  Never when several query groups re-read a page chunk from L2.
 __device__ __forceinline__ void lds_dma_16B_sbase_nt(const void* sbase, uint32_t voff, uint32_t lds_base) {
+    sentinel_fill(lds_base);
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -62,6 +84,27 @@ __device__ __forceinline__ void lds_dma_16B_sbase_nt(const void* sbase, uint32_t
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- stage hand-over of an LDS-DMA ring: ONE statement, ordered by construction ------------------------------------
+// RAW (a stage's data before any wave reads it): every wave retires its own pieces of the stage (all but its N youngest
+// vector-memory operations) and only then arrives at the barrier; a reader has passed the barrier, hence every wave's wait.
+// WAR (a slot's last reads before its refill): the refill of a slot is issued behind a LATER ring_barrier than the
+// stage that read it; lgkmcnt(0) in front of the barrier retires every ds_read the wave has issued so far -- also those
+// whose consumers the scheduler may have placed after the barrier -- so no read of the old tenant is in flight when any wave
+// passes.  Waits and s_barrier sit in one volatile asm with a memory clobber: the compiler can neither put an LDS access
+// between them nor move one across them (the bare __builtin_amdgcn_s_barrier() is IntrNoMem to LLVM: no fence at all), and no
+// schedule change or recompile can take the order apart (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the
+// wait that retires it"; scratch/audit_ring_isa.py checks every instance's listing for exactly this form).
+template <int N>
+__device__ __forceinline__ void ring_barrier() {
+#if defined(EVDR_RING_FAULT)
+    // positive control of the sentinel instrument (scratch/sentinel_control.py; never a shipped build, and
+    // scratch/audit_ring_isa.py rejects it): the hand-over WITHOUT its vmcnt wait, i.e. a deliberate read-before-landed race
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
 }
 
 // ---- cross-lane reductions for the page epilogue, at VALU speed (no LDS round trips) ------------------------------

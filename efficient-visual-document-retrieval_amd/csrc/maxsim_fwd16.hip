@@ -186,12 +186,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
     int slot = 0;
     for (int s = 0; s < nstages; ++s) {
         // stage s has landed once only the younger stages' pieces (NSTAGE-2 of them in steady state) remain
+        // (waits + barrier as one statement: ring_barrier, maxsim_device.h)
         if (NSTAGE >= 3 && s + 1 < nstages) {
-            if (NSTAGE >= 4 && s + 2 < nstages) wait_vmcnt<2 * G>(); else wait_vmcnt<G>();
+            if (NSTAGE >= 4 && s + 2 < nstages) ring_barrier<2 * G>(); else ring_barrier<G>();
         } else {
-            wait_vmcnt<0>();
+            ring_barrier<0>();
         }
-        __builtin_amdgcn_s_barrier();
         if (s + NSTAGE - 1 < nstages) issue_stage(s + NSTAGE - 1, slot == 0 ? NSTAGE - 1 : slot - 1);
         const char* sbase = smem + slot * STAGE_BYTES;
         if (active) {
@@ -787,8 +787,9 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                 }
             }
             if constexpr (DIAG) { d_a = stamp(); d_ctl += d_a - d_c0; }
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
+            // stage hand-over (ring_barrier, maxsim_device.h): this wave's pieces of the stage have landed and every ds_read it
+            // has issued is retired BEFORE it arrives; nothing can be scheduled into or across the statement
+            ring_barrier<0>();
             if constexpr (DIAG) { const unsigned long long t = stamp(); d_bar += t - d_a; d_a = t; }
             if (refill && !spread) {
                 if (next_rows) {                                        // no row of the stage needs clamping: constant offsets
