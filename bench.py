@@ -49,7 +49,7 @@ def gen_pages(lo: int, hi: int, dev) -> torch.Tensor:
     return out
 
 
-def make_queries(nq: int, n_pages: int, shard, lo: int, hi: int, dev, world: int):
+def make_queries(nq: int, n_pages: int, shard, lo: int, hi: int, dev, world: int, group=None):
     """Planted queries: query i targets page t_i = (i*7919) mod N; token n = normalise(P[t_i, pi_i(n)]
     + 0.5 eps).  Each rank fills the queries whose target lives in its shard; an all-reduce (setup, untimed) sums."""
     import torch.distributed as dist
@@ -64,12 +64,12 @@ def make_queries(nq: int, n_pages: int, shard, lo: int, hi: int, dev, world: int
         base = shard[t_local[:, None], rows[mine].to(dev)].float()                          # (m, LQ, D)
         Q[mine.to(dev)] = torch.nn.functional.normalize(base + 0.5 * eps[mine].to(dev), dim=-1)
     if world > 1:
-        if dist.get_backend() == "gloo":
+        if dist.get_backend(group) == "gloo":
             host = Q.cpu()
-            dist.all_reduce(host)
+            dist.all_reduce(host, group=group)
             Q = host.to(dev)
         else:
-            dist.all_reduce(Q)
+            dist.all_reduce(Q, group=group)
     return Q.bfloat16(), targets
 
 
@@ -267,31 +267,39 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend, fallback_reason, ranks_seen = args.backend, None, 1
+    group = None                                      # the DATA group: candidates, score columns, barriers, the step clock
     if world > 1:
         import datetime
+        # The default group is ALWAYS gloo: a control plane that needs no GPU and cannot fail the way a first RCCL run can.  The
+        # data group (nccl = RCCL over xGMI) is formed next to it, and whether it is usable is AGREED over the control plane: every
+        # rank min-reduces its own verdict, so either all ranks use RCCL or all of them fall back to gloo through host memory
+        # (0.8 MB per rank and step) -- a one-sided failure can no longer split the job between two backends -- and the line says
+        # which it was.  The control group's timeout is longer than the data group's: a rank whose RCCL probe failed at once
+        # waits there for the ranks whose probe is still running into its timeout.
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+        ok_mine, why = 1, None
         if backend == "nccl":
-            # the first RCCL run with N > 1 happens on the driver's node, not in the build loop: if the communicator cannot
-            # be formed (an exception, on every rank alike), the exchange falls back to gloo through host memory -- 0.8 MB
-            # per rank and step -- and the line says so, instead of the run producing no record at all
             try:
-                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
+                group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=240), device_id=dev)
                 probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe)
+                dist.all_reduce(probe, group=group)
+                torch.cuda.synchronize()
                 ranks_seen = int(probe.item())
+                ok_mine = int(ranks_seen == world)
+                why = None if ok_mine else f"RCCL all-reduce saw {ranks_seen} of {world} ranks"
             except Exception as e:                       # noqa: BLE001
-                fallback_reason = f"{type(e).__name__}: {str(e)[:300]}"
-                try:
-                    dist.destroy_process_group()
-                except Exception:                        # noqa: BLE001
-                    pass
-                # a fresh store next door, hosted by rank 0 itself (under torchrun the first one lives in the agent)
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-                os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"
-                backend = "gloo"
+                ok_mine, why = 0, f"{type(e).__name__}: {str(e)[:300]}"
+            verdict = torch.tensor([ok_mine], dtype=torch.int32)
+            dist.all_reduce(verdict, op=dist.ReduceOp.MIN)            # control plane (gloo)
+            if int(verdict.item()) == 0:
+                reasons = [None] * world
+                dist.all_gather_object(reasons, why)
+                fallback_reason = "; ".join(f"rank {r}: {w}" for r, w in enumerate(reasons) if w) or "a peer rank could not use RCCL"
+                backend, group = "gloo", None
         if backend == "gloo":
-            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+            group = dist.group.WORLD
             probe = torch.ones(1)
-            dist.all_reduce(probe)
+            dist.all_reduce(probe, group=group)
             ranks_seen = int(probe.item())
 
     import evdr_amd  # noqa: F401
@@ -303,17 +311,17 @@ def main():
     lo, hi = shard_range(args.pages, rank, world)
     shard_pages = gen_pages(lo, hi, dev)
     corpus = PageCorpus.from_tensor(shard_pages, None, idx_base=lo)
-    Q, targets = make_queries(args.queries, args.pages, shard_pages, lo, hi, dev, world)
-    retriever = ShardedRetriever(corpus)
+    Q, targets = make_queries(args.queries, args.pages, shard_pages, lo, hi, dev, world, group)
+    retriever = ShardedRetriever(corpus, group)
 
     def step():
         return retriever.search(Q, None, args.topk)
 
     def barrier():
         if backend == "nccl":
-            dist.barrier(device_ids=[dev_index])       # this rank's GPU, stated explicitly
+            dist.barrier(group=group, device_ids=[dev_index])       # this rank's GPU, stated explicitly
         else:
-            dist.barrier()
+            dist.barrier(group=group)
 
     def fence():
         if world > 1:
@@ -322,15 +330,20 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    corpus.score_events = []        # the dominant kernel of every TIMED step bracketed by HIP events on its launch stream
+    for _ in range(min(2, args.warmup)):
+        step()                      # (warm the bracketed form of the step as well: the first event pair allocates)
+    corpus.score_events.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts, ti = step()
     fence()
     elapsed = time.perf_counter() - t0
+    step_events, corpus.score_events = corpus.score_events, None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(tmax.item())
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     pairs_per_step = args.queries * args.pages
@@ -342,27 +355,45 @@ def main():
     from evdr_amd import ops as _ops
     from evdr_amd.corpus import gather_candidates, merge_candidates
 
+    def all_ranks_ok(ok: bool) -> bool:
+        """Control-plane agreement (gloo default group): True only if EVERY rank says ok -- taken before a section that holds
+        collectives, so that a rank which failed locally makes all ranks skip it together instead of leaving its peers waiting
+        in the collective for their timeout."""
+        if world == 1:
+            return ok
+        v = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        return bool(v.item())
+
     def phase_breakdown(reps=3):
         acc = [0.0, 0.0, 0.0, 0.0]
-        sbuf = torch.empty((args.queries, corpus.n_pages), dtype=torch.float32, device=dev)
+        sbuf = None
         for _ in range(reps):
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-            e[0].record()
-            corpus.score(Q, None, out=sbuf)
-            e[1].record()
-            if corpus.n_pages:
-                ls, li = _ops.topk(sbuf, args.topk, idx_base=corpus.idx_base)
-            else:
-                ls, li = corpus.topk(Q, None, args.topk)
-            e[2].record()
-            torch.cuda.synchronize()
-            acc[0] += e[0].elapsed_time(e[1])
-            acc[1] += e[1].elapsed_time(e[2])
+            err = None
+            try:                                           # device phases: local to this rank
+                if sbuf is None:
+                    sbuf = torch.empty((args.queries, corpus.n_pages), dtype=torch.float32, device=dev)
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                e[0].record()
+                corpus.score(Q, None, out=sbuf)
+                e[1].record()
+                if corpus.n_pages:
+                    ls, li = _ops.topk(sbuf, args.topk, idx_base=corpus.idx_base)
+                else:
+                    ls, li = corpus.topk(Q, None, args.topk)
+                e[2].record()
+                torch.cuda.synchronize()
+                acc[0] += e[0].elapsed_time(e[1])
+                acc[1] += e[1].elapsed_time(e[2])
+            except Exception as ex:                        # noqa: BLE001
+                err = ex
+            if not all_ranks_ok(err is None):
+                raise err if err is not None else RuntimeError("a peer rank failed in the device phases")
             if world > 1:
                 barrier()
                 torch.cuda.synchronize()
                 th = time.perf_counter()
-                sc, ix = gather_candidates(ls, li)
+                sc, ix = gather_candidates(ls, li, group)
                 torch.cuda.synchronize()
                 acc[2] += (time.perf_counter() - th) * 1e3
                 e[3].record()
@@ -373,37 +404,36 @@ def main():
         mine = torch.tensor([a / reps for a in acc], dtype=torch.float64)
         worst = mine.clone()
         if world > 1:
-            w = worst.to(dev) if backend == "nccl" else worst
-            dist.all_reduce(w, op=dist.ReduceOp.MAX)
-            worst = w.cpu()
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)          # control plane (host tensor)
         names = ("score_ms", "topk_ms", "exchange_ms", "merge_ms")
         keep = 4 if world > 1 else 2
         return {"rank0": {n: float(v) for n, v in zip(names[:keep], mine[:keep])},
                 "max_over_ranks": {n: float(v) for n, v in zip(names[:keep], worst[:keep])},
-                "note": "separate instrumented passes after the timed region (score and top-k as two calls; the timed step "
-                        "issues them through one C-ABI call), mean of %d" % reps}
+                "note": "separate instrumented passes after the timed region (score and top-k as two calls), mean of %d" % reps}
     # everything after the timed region is evidence around the headline number: a failure there is recorded in the line, it
     # must not cost the line itself (the first N > 1 run happens where nobody can re-run it)
+    device_errors = []
+
     def guarded(what, fn):
         try:
             return fn()
         except Exception as e:                              # noqa: BLE001
-            print(f"bench.py: {what} failed: {type(e).__name__}: {e}", file=sys.stderr)
-            return {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            msg = f"{type(e).__name__}: {e}"
+            print(f"bench.py: {what} failed: {msg}", file=sys.stderr)
+            # a HIP / accelerator error is sticky: the line is still printed (the timed region was clean), but the process must
+            # not report success -- it exits 3 after the line
+            if any(k in msg for k in ("HIP", "hip", "CUDA", "accelerator", "libevdr status 4", "device-side")):
+                device_errors.append(f"{what}: {msg[:200]}")
+            return {"error": msg[:300]}
     phases = guarded("phase breakdown", phase_breakdown)
 
-    # ---- roofline of the dominant kernel: HIP events around the MaxSim launch on its own stream
+    # ---- roofline of the dominant kernel: HIP events around the MaxSim launch on its launch stream, INSIDE the timed steps
+    # (one pair per step, recorded by PageCorpus.topk; every bracket lies inside its step, so their mean cannot exceed ms_per_step)
     out = torch.empty((args.queries, corpus.n_pages), dtype=torch.float32, device=dev)
-    corpus.score(Q, None, out=out)
+    corpus.score(Q, None, out=out)                      # (the score block the CPU leg below is checked against)
     torch.cuda.synchronize()
-    reps = 3
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in ev:
-        a.record()
-        corpus.score(Q, None, out=out)
-        b.record()
-    torch.cuda.synchronize()
-    k_ms = sum(a.elapsed_time(b) for a, b in ev) / reps
+    k_each = [a.elapsed_time(b) for a, b in step_events]
+    k_ms = sum(k_each) / max(len(k_each), 1)
     flop_per_launch = args.queries * corpus.n_pages * FLOP_PER_PAIR
     achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
     from evdr_amd import _lib as L
@@ -429,6 +459,7 @@ def main():
     roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kernel_symbol, "kernel_ms": k_ms,
+                "kernel_ms_basis": f"mean of {len(k_each)} launches, one per TIMED step, HIP events on the launch stream inside the timed region",
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "algorithmic_bytes_per_launch": corpus.n_pages * LP * D * 2}
 
@@ -483,18 +514,22 @@ def main():
                        "query_tokens": LQ, "topk": args.topk, "parallelism": f"page-shard x{world}"},
             "queries_per_sec": args.queries / (ms_per_step * 1e-3), "ndcg_at_5": ndcg5,
             "dist": {"world_size": dist.get_world_size() if world > 1 else 1, "ranks_seen": ranks_seen,
-                     "backend": dist.get_backend() if world > 1 else None, "backend_requested": args.backend if world > 1 else None,
+                     "backend": dist.get_backend(group) if world > 1 else None, "control_backend": "gloo" if world > 1 else None,
+                     "backend_requested": args.backend if world > 1 else None,
                      "backend_fallback_reason": fallback_reason, "launcher": launcher,
                      "exchange": "all_gather_into_tensor of (nq, 2k) int32 per rank" if world > 1 else None,
                      "pages_per_rank": corpus.n_pages},
             "phases": phases,
             "roofline": roofline, "cpu_baseline": cpu_base,
             "train_step": train_step, "eval": eval_rec,
+            "device_errors_after_timed_region": device_errors or None,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
-        barrier()
+        dist.barrier()                                 # control plane: leaves together whatever happened to the data group
         dist.destroy_process_group()
+    if device_errors:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -170,6 +170,25 @@ def kernel_rooflines(inp, reps: int = 30):
                 "algorithmic_tflops": alg / ms / 1e9, "frac_algorithmic_vs_fp16_peak": alg / ms / 1e9 / MFMA_F16_PEAK,
                 "algorithmic_vs_fp32_mfma_peak": alg / ms / 1e9 / MFMA_F32_PEAK}
 
+    ins = in_step_kernel_ms(inp)
+
+    def both(entry, role):
+        # kernel_ms: the kernel ALONE, `reps` launches back to back; kernel_ms_in_step: the same kernel inside the fused step
+        ms_in = ins[role]
+        work = entry.get("executed_flop_per_launch") or entry["algorithmic_bytes_per_launch"]
+        scale = 1e9 if entry["bound"] == "mfma" else 1e6
+        entry["kernel_ms_basis"] = f"alone, {reps} launches back to back (HIP events on the launch stream)"
+        entry["kernel_ms_in_step"] = ms_in
+        entry["achieved_in_step"] = work / ms_in / scale
+        entry["frac_in_step"] = work / ms_in / scale / entry["peak"]
+        entry["kernel_ms_in_step_basis"] = (f"inside the fused step (fused_nosync), HIP events around each launch, mean of "
+                                            f"{ins['launches'][role]} steps; step with the events {ins['ms_per_step_with_events']:.4f} ms")
+        return entry
+
+    return [both(e, r) for e, r in zip(_entries(mfma_entry, t_kernel, t_ms, s_kernel, s_ms, u_ms, u_bytes), ("teacher", "student", "update"))]
+
+
+def _entries(mfma_entry, t_kernel, t_ms, s_kernel, s_ms, u_ms, u_bytes):
     return [
         mfma_entry(t_kernel, "teacher forward (fp32 as fp16 hi/lo planes)", t_ms, LT),
         mfma_entry(s_kernel, "student forward + argmax", s_ms, LS),
@@ -179,6 +198,50 @@ def kernel_rooflines(inp, reps: int = 30):
          "frac": u_bytes / u_ms / 1e6 / HBM_PEAK, "frac_basis": "algorithmic bytes / 8 TB/s HBM3E spec",
          "algorithmic_bytes_per_launch": u_bytes},
     ]
+
+
+def in_step_kernel_ms(inp, steps: int = 40, warmup: int = 10):
+    """The same three kernels timed INSIDE the fused step (fused_nosync: the host queues ahead, nothing waits): a HIP event
+    in front of and behind each launch on the launch stream, averaged over `steps` steps.  What differs from the
+    back-to-back figure: the kernel in front is a different one (caches, clocks and the power state are the step's, not
+    those of 30 repetitions of one kernel), and the few us between two launches are inside the bracket."""
+    from evdr_amd import driver, ops
+    B, Pt, pmt, pms, Pbar0, Qall, qmall = inp["B"], inp["Pt"], inp["pmt"], inp["pms"], inp["Pbar0"], inp["Qall"], inp["qmall"]
+    teacher = driver.TeacherScorer(Pt, pmt)
+    student = driver.FusedStudent(Pbar0.clone(), pms, lr=1e-3, weight_decay=1e-2)
+    rec = {"teacher": [], "student": [], "update": []}
+    live = [False]
+    orig_f, orig_u = ops.maxsim_forward_prepared, ops.maxsim_backward_adamw
+
+    def bracket(role, fn, *a, **k):
+        if not live[0]:
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        rec[role].append((e0, e1))
+        return r
+
+    ops.maxsim_forward_prepared = lambda *a, **k: bracket("student" if k.get("want_argmax") else "teacher", orig_f, *a, **k)
+    ops.maxsim_backward_adamw = lambda *a, **k: bracket("update", orig_u, *a, **k)
+    try:
+        t_step = None
+        for i in range(warmup + steps):
+            if i == warmup:
+                torch.cuda.synchronize()
+                live[0] = True
+                t0 = time.perf_counter()
+            lo = (i % 64) * B
+            driver.fused_train_one_step(Qall[lo:lo + B], qmall[lo:lo + B], teacher, student, 0.1, sync=False)
+        torch.cuda.synchronize()
+        t_step = 1e3 * (time.perf_counter() - t0) / steps
+    finally:
+        ops.maxsim_forward_prepared, ops.maxsim_backward_adamw = orig_f, orig_u
+    out = {role: sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1) for role, evs in rec.items()}
+    out["launches"] = {role: len(evs) for role, evs in rec.items()}
+    out["ms_per_step_with_events"] = t_step
+    return out
 
 
 def cpu_baseline(inp, n_pages: int, reps: int = 1):
@@ -207,12 +270,13 @@ def cpu_baseline(inp, n_pages: int, reps: int = 1):
 
 
 def measure(pages: int = 500, batch: int = 32, steps: int = 50, warmup: int = 25, kinds=None, cpu_pages: int = 500,
-            cpu_reps: int = 2, dev=None):
+            cpu_reps: int = 2, dev=None, roofline: bool = True):
     """The configs[4] record: modes -> ms/step, kernel rooflines, CPU baseline."""
     dev = dev or torch.device("cuda:0")
     inp = make_inputs(pages, batch, dev)
     res = {kind: time_mode(inp, kind, steps, warmup) for kind in (kinds or ALL_KINDS)}
-    roof = kernel_rooflines(inp)
+    # roofline=False: a profiler run whose kernel statistics are then the timed steps' own kernels and nothing else
+    roof = kernel_rooflines(inp) if roofline else None
     cpu = cpu_baseline(inp, cpu_pages, cpu_reps) if cpu_pages > 0 else None
     return {"config": {"workload": "mainv2_iter_distill_infonce step (BASELINE.json configs[4])", "pages": pages,
                        "batch_queries": batch, "teacher_patches": LT, "student_patches": LS, "steps": steps, "warmup": warmup},
@@ -234,12 +298,14 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--only", type=str, default="", help="comma list of modes to run (default: all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel repetitions (rocprofv3 runs: the trace then holds the steps' kernels only)")
     a = ap.parse_args()
     import evdr_amd  # noqa: F401
     kinds = ALL_KINDS + (["eager"] if a.eager else [])
     if a.only:
         kinds = [k for k in kinds if k in a.only.split(",")]
-    rec = measure(a.pages, a.batch, a.steps, a.warmup, kinds, cpu_pages=0 if a.no_cpu_baseline else a.pages)
+    rec = measure(a.pages, a.batch, a.steps, a.warmup, kinds, cpu_pages=0 if a.no_cpu_baseline else a.pages,
+                  roofline=not a.no_roofline)
     res = rec["results"]
     head = "fused" if "fused" in res else (kinds[0] if kinds else None)
     print(json.dumps({"metric": "InfoNCE-distillation steps/sec (mainv2_iter_distill_infonce.py train_one_step)",

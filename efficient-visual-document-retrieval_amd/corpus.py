@@ -46,6 +46,9 @@ class PageCorpus:
         self.p_stride, self.p_plane_stride = int(planes.stride(1)), int(planes.stride(0))
         self.device = planes.device
         self._ws: Optional[torch.Tensor] = None       # score workspace of topk(), kept between calls (410 MB at 1024 x 100k)
+        # bench.py: a list here makes topk() bracket its MaxSim launch with HIP events on the launch stream and append the
+        # pair -- the scorer's own share of every TIMED step (the same two kernels, issued as two C-ABI calls instead of one)
+        self.score_events: Optional[list] = None
 
     @classmethod
     def from_tensor(cls, P: torch.Tensor, pmask: Optional[torch.Tensor] = None, idx_base: int = 0) -> "PageCorpus":
@@ -106,6 +109,21 @@ class PageCorpus:
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = ops.workspace(need, dev)       # allocated once per (corpus, batch size), not per search
         ws = self._ws
+        if self.score_events is not None:
+            sc_bytes = (nq * self.n_pages * 4 + 255) // 256 * 256        # evdr_maxsim_topk's own carving of the workspace
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with L.on(dev):
+                stream = L.current_stream_handle(dev)
+                e0.record()
+                L.check(lib.evdr_maxsim_fwd_prepared(
+                    L.ptr(qp), L.ptr(self.planes), L.ptr(qm), L.ptr(self.tilemask), L.ptr(self.pageflags), ws.data_ptr(), self.n_pages,
+                    None, nq, lq, self.n_pages, self.lp, self.nplanes, self.p_stride, self.p_plane_stride, L.ptr(qamax), L.ptr(self.amax),
+                    None, stream))
+                e1.record()
+                L.check(lib.evdr_topk(ws.data_ptr(), None, nq, self.n_pages, self.n_pages, self.idx_base, k, L.ptr(ts), L.ptr(ti),
+                                      ws.data_ptr() + sc_bytes, lib.evdr_topk_workspace(nq, self.n_pages, L.EVDR_TOPK_MAX), stream))
+            self.score_events.append((e0, e1))
+            return ts, ti
         with L.on(dev):
             L.check(lib.evdr_maxsim_topk(
                 L.ptr(qp), L.ptr(self.planes), L.ptr(qm), L.ptr(self.tilemask), L.ptr(self.pageflags),

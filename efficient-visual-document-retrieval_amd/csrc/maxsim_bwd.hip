@@ -13,12 +13,21 @@ constexpr int BW_THREADS = 512;
 
 // One workgroup owns BW_ROWS consecutive patch rows of one page.  fp32 LDS atomics are NOT the accumulation path:
 // ds_add_f32 costs ~175 cycles per wave-instruction on gfx950 (measured: 346 us with one atomic per pair, 28 us with plain
-// read-modify-write on this very kernel).  Instead the (query, token) pairs are bucketed by target row -- integer
-// histogram, exclusive scan, scatter: three small LDS passes per chunk of pairs -- and the sorted list is cut into equal
-// slices (snapped to bucket starts), one per 16-lane group: a group walks its slice with four 512-B query-row loads in
-// flight, accumulates a row in registers and adds it into the slab with plain LDS accesses; only a row heavier than a
-// whole slice is shared between groups, and only its partial sums go through LDS atomics.  Every dP element is written to HBM exactly once; masked rows come out as exact zeros.
-// The order of the additions inside one row follows the scatter order (not fixed run to run, like index_add_ on a GPU).
+// read-modify-write on this very kernel).  Instead the (query, token) pairs are bucketed by target row -- a STABLE counting
+// sort: per (row, wave-instruction) counts, exclusive scan, scatter by rank: three small LDS passes per chunk of pairs -- and
+// the sorted list is cut into equal slices (snapped to bucket starts), one per 16-lane group: a group walks its slice with
+// four 512-B query-row loads in flight, accumulates a row in registers and adds it into the slab with plain LDS accesses;
+// only a row heavier than a whole slice is shared between groups.  Every dP element is written to HBM exactly once; masked
+// rows come out as exact zeros.
+// BIT-REPRODUCIBLE (the reference's CPU backward is): the order of the additions into one dP row is a function of the
+// inputs alone, never of timing --
+//   * inside a bucket the pairs stand in ascending (query, token) order: a pair's slot is bucket start + pairs of the same
+//     row in earlier wave-instructions (byte counters per (row, instruction): integer adds, order-free) + its rank among the
+//     lanes of its own instruction with the same row (a lane match in registers: 7 ballots, v_mbcnt) -- no cursor atomics whose
+//     return value depends on who came first;
+//   * a row shared by several groups (heavier than a slice) is summed in GROUP order: each group keeps the partial sum of a
+//     row it shares in registers and the groups add them to the slab in ordered rounds (round t = the t-th group of the
+//     row, plain read-modify-write, one barrier per round; no round at all when no row is shared) -- no float atomics.
 // FUSED: instead of writing dP (the gradient w.r.t. the NORMALISED pages), the epilogue continues on the slab in LDS:
 // l2-normalise backward through y = m x / (||m x|| + eps_n)  ->  AdamW on the raw parameter x (torch semantics: decoupled
 // weight decay, bias-corrected moments), in place on x / exp_avg / exp_avg_sq.  One kernel replaces maxsim_bwd + the
@@ -98,17 +107,22 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
                                                                AdamArgs ad) {
     constexpr int PER_THREAD = CHUNK / BW_THREADS;
     constexpr int NGROUPS = BW_THREADS / 16;
+    constexpr int NWAVES = BW_THREADS / 64;
+    constexpr int NSLOTS = PER_THREAD * NWAVES;                          // wave-instructions that bucket pairs, per chunk
+    constexpr int CW = (NSLOTS + 3) / 4;                                 // counter words per row (one byte per slot: <= 64 lanes)
+    static_assert(CHUNK % BW_THREADS == 0 && BW_ROWS <= 128 && BW_ROWS <= BW_THREADS, "bucket geometry");
     extern __shared__ __attribute__((aligned(16))) float acc[];          // [BW_ROWS][128]
     int* list = reinterpret_cast<int*>(acc + BW_ROWS * EVDR_D);          // [CHUNK] pair index inside the chunk, bucketed
     float* wl = reinterpret_cast<float*>(list + CHUNK);                  // [CHUNK] weight of list[k]
     int* hist = reinterpret_cast<int*>(wl + CHUNK);                      // [BW_ROWS] bucket sizes
     int* offs = hist + BW_ROWS;                                          // [BW_ROWS] bucket starts
-    int* cur = offs + BW_ROWS;                                           // [BW_ROWS] scatter cursors
-    __shared__ int sh_has, sh_total;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(offs + BW_ROWS);         // [BW_ROWS][CW] pairs per (row, slot), one byte each
+    __shared__ int sh_has, sh_total, sh_rounds;
     const int page = blockIdx.x;
     const int r0 = blockIdx.y * BW_ROWS;
     const int rows = min(BW_ROWS, lp - r0);
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = tid >> 6;
     const int gid = tid >> 4, sub = tid & 15;
 
     if (tid == 0) sh_has = (pmask == nullptr) ? 1 : 0;
@@ -120,13 +134,16 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
         if (any) sh_has = 1;                              // benign race: every writer stores 1
     }
     __syncthreads();
+    auto bytesum = [](uint32_t x) { return (int)((x & 0xFFu) + ((x >> 8) & 0xFFu) + ((x >> 16) & 0xFFu) + (x >> 24)); };
     if (sh_has) {
         const int npairs = nq * lq;
         for (int c0 = 0; c0 < npairs; c0 += CHUNK) {
-            for (int r = tid; r < BW_ROWS; r += BW_THREADS) { hist[r] = 0; cur[r] = 0; }
+            for (int r = tid; r < BW_ROWS * CW; r += BW_THREADS) cnt[r] = 0u;
+            if (tid == 0) sh_rounds = 0;
             __syncthreads();
-            // (1) this thread's pairs: target row inside the slab (or -1) and weight g * qmask; bucket sizes
-            int a_loc[PER_THREAD];
+            // (1) this thread's pairs: target row inside the slab (or -1), weight g * qmask, and the pair's RANK among the
+            // lanes of this wave-instruction that hit the same row; per (row, instruction) counts
+            int a_loc[PER_THREAD], rank_loc[PER_THREAD];
             float w_loc[PER_THREAD];
 #pragma unroll
             for (int k = 0; k < PER_THREAD; ++k) {
@@ -140,14 +157,32 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
                     if (qmask != nullptr && qmask[i] == 0) w = 0.f;
                     if (a < 0 || a >= rows || w == 0.f) a = -1;
                 }
+                // lanes of this instruction with the same row: AND over the 7 row bits of (bit set ? ballot : ~ballot)
+                unsigned long long same = __ballot(a >= 0);
+#pragma unroll
+                for (int b = 0; b < 7; ++b) {
+                    const bool bit = (a >> b) & 1;
+                    const unsigned long long bb = __ballot(bit);
+                    same &= bit ? bb : ~bb;
+                }
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
                 a_loc[k] = a;
                 w_loc[k] = w;
-                if (a >= 0) atomicAdd(&hist[a], 1);
+                rank_loc[k] = rank;
+                if (a >= 0 && rank == 0) {                              // one lane per row: integer add, order-free
+                    const int slot = k * NWAVES + wave;
+                    atomicAdd(&cnt[a * CW + (slot >> 2)], (uint32_t)__popcll(same) << (8 * (slot & 3)));
+                }
             }
             __syncthreads();
-            // (2) exclusive scan of the bucket sizes (BW_ROWS <= BW_THREADS: one element per thread, Hillis-Steele)
-            int v = (tid < BW_ROWS) ? hist[tid] : 0;
-            if (tid < BW_ROWS) offs[tid] = v;
+            // (2) bucket sizes and their exclusive scan (BW_ROWS <= BW_THREADS: one element per thread, Hillis-Steele)
+            int v = 0;
+            if (tid < BW_ROWS) {
+#pragma unroll
+                for (int wd = 0; wd < CW; ++wd) v += bytesum(cnt[tid * CW + wd]);
+                hist[tid] = v;
+                offs[tid] = v;
+            }
             __syncthreads();
             for (int o = 1; o < BW_ROWS; o <<= 1) {
                 int add = (tid < BW_ROWS && tid >= o) ? offs[tid - o] : 0;
@@ -158,14 +193,22 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
             if (tid == BW_ROWS - 1) sh_total = offs[tid];  // all bucketed pairs of this chunk
             if (tid < BW_ROWS) offs[tid] -= v;            // inclusive -> exclusive
             __syncthreads();
-            // (3) scatter the pairs into their buckets
+            // (3) scatter: bucket start + pairs of the row in earlier instructions + rank inside this one = ascending pair order
 #pragma unroll
             for (int k = 0; k < PER_THREAD; ++k) {
                 const int a = a_loc[k];
                 if (a >= 0) {
-                    const int slot = offs[a] + atomicAdd(&cur[a], 1);
-                    list[slot] = (k * BW_THREADS + tid) | (a << 16);       // pair inside the chunk | target row
-                    wl[slot] = w_loc[k];
+                    const int slot = k * NWAVES + wave;                 // wave-uniform
+                    int before = 0;
+#pragma unroll
+                    for (int wd = 0; wd < CW; ++wd) {
+                        const uint32_t c = cnt[a * CW + wd];
+                        if (wd < (slot >> 2)) before += bytesum(c);
+                        else if (wd == (slot >> 2)) before += bytesum(c & ((1u << (8 * (slot & 3))) - 1u));
+                    }
+                    const int pos = offs[a] + before + rank_loc[k];
+                    list[pos] = (k * BW_THREADS + tid) | (a << 16);        // pair inside the chunk | target row
+                    wl[pos] = w_loc[k];
                 }
             }
             __syncthreads();
@@ -173,13 +216,14 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
             // whatever the distribution over rows: a patch that wins half of a page's (query, token) pairs -- salient
             // patches do -- no longer serialises on one group (all pairs on one row: 220 us before, now the uniform-case
             // time).  A group accumulates a row in registers with 4 query-row loads in flight and adds it into the slab when
-            // the row changes: plain read-modify-write if the whole bucket lies in its slice, LDS float atomics for a
-            // heavy row it shares with its neighbours.
+            // the row changes: plain read-modify-write if the whole bucket lies in its slice.  The partial sum of a heavy row
+            // it shares with its neighbours stays in registers -- `head`: a row that began in an earlier group's slice,
+            // `tail`: a row that continues into the next group's -- and joins the slab in the ordered rounds below.
             {
                 const int total = sh_total;
                 const int per = ((total + NGROUPS - 1) / NGROUPS + 3) & ~3;
                 // slice boundary g: g * per, moved back to the start of the bucket it falls into unless that bucket is
-                // larger than a slice -- so only rows heavier than a slice are ever shared (and pay atomics)
+                // larger than a slice -- so only rows heavier than a slice are ever shared
                 auto boundary = [&](int gi) {
                     const int x = gi * per;
                     if (x <= 0) return 0;
@@ -190,19 +234,24 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
                 const int lo = boundary(gid), hi = boundary(gid + 1);
                 int cur_row = -1;
                 f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+                int head_row = -1, head_turn = 0, tail_row = -1;
+                f32x4 h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0}, t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
                 auto flush = [&]() {
                     if (cur_row < 0) return;
-                    float* dst = acc + cur_row * EVDR_D + sub * 8;
                     const int b0 = offs[cur_row];
                     if (b0 >= lo && b0 + hist[cur_row] <= hi) {
+                        float* dst = acc + cur_row * EVDR_D + sub * 8;
                         reinterpret_cast<f32x4*>(dst)[0] += s0;
                         reinterpret_cast<f32x4*>(dst)[1] += s1;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            atomicAdd(dst + i, s0[i]);
-                            atomicAdd(dst + 4 + i, s1[i]);
-                        }
+                    } else if (b0 < lo) {               // began in an earlier slice (only ever the first row of this one): this group
+                        head_row = cur_row;             // is the row's (gid - first group)-th contributor; the first group of a heavy
+                        head_turn = gid - b0 / per;     // row is the one whose slice holds its bucket start: floor(b0 / per)
+                        h0 = s0;
+                        h1 = s1;
+                    } else {                            // begins here, continues in the next slice: the row's first contributor
+                        tail_row = cur_row;
+                        t0 = s0;
+                        t1 = s1;
                     }
                 };
                 for (int k = lo; k < hi; k += 4) {
@@ -234,8 +283,27 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
                     }
                 }
                 flush();
+                // ordered rounds over the shared rows: round 0 = every row's first contributor (tails: distinct rows), round
+                // t = its t-th (heads with turn t: one group per row and round), plain read-modify-write, a barrier between
+                // rounds.  The number of rounds is the longest chain of groups over one row (0 when nothing is shared).
+                const int need = max(tail_row >= 0 ? 1 : 0, head_row >= 0 ? head_turn + 1 : 0);
+                if (need > 0 && sub == 0) atomicMax(&sh_rounds, need);
+                __syncthreads();
+                const int rounds = sh_rounds;
+                for (int t = 0; t < rounds; ++t) {
+                    if (t == 0 && tail_row >= 0) {
+                        float* dst = acc + tail_row * EVDR_D + sub * 8;
+                        reinterpret_cast<f32x4*>(dst)[0] += t0;
+                        reinterpret_cast<f32x4*>(dst)[1] += t1;
+                    }
+                    if (t > 0 && head_row >= 0 && head_turn == t) {
+                        float* dst = acc + head_row * EVDR_D + sub * 8;
+                        reinterpret_cast<f32x4*>(dst)[0] += h0;
+                        reinterpret_cast<f32x4*>(dst)[1] += h1;
+                    }
+                    __syncthreads();
+                }
             }
-            __syncthreads();
         }
     }
     if constexpr (!FUSED) {
@@ -598,7 +666,8 @@ __global__ void __launch_bounds__(256) mean_kernel(const float* __restrict__ x, 
 template <int BW_ROWS, int CHUNK, bool FUSED>
 static hipError_t launch_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,
                              float* dP, int64_t nq, int64_t lq, int64_t np, int64_t lp, const AdamArgs& ad, hipStream_t stream) {
-    constexpr int LDS = BW_ROWS * EVDR_D * 4 + CHUNK * 8 + BW_ROWS * 12;
+    constexpr int CW = (CHUNK / BW_THREADS * (BW_THREADS / 64) + 3) / 4;
+    constexpr int LDS = BW_ROWS * EVDR_D * 4 + CHUNK * 8 + BW_ROWS * 8 + BW_ROWS * CW * 4;
     auto kern = maxsim_bwd_kernel<BW_ROWS, CHUNK, FUSED>;
     static uint64_t attr_devs = 0;
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;

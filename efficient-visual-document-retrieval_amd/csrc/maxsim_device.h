@@ -102,6 +102,9 @@ __device__ __forceinline__ void ring_barrier() {
     // positive control of the sentinel instrument (scratch/sentinel_control.py; never a shipped build, and
     // scratch/audit_ring_isa.py rejects it): the hand-over WITHOUT its vmcnt wait, i.e. a deliberate read-before-landed race
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#elif defined(EVDR_RING_NOLGKM)
+    // A/B only (scratch/r04_ab_hardening.sh): what the lgkmcnt(0) of the hand-over costs; rejected by scratch/audit_ring_isa.py
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 #else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 #endif

@@ -722,6 +722,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             }
         }
         const bool page_close = (k + 1 == khi);
+        bool load_apf = false;
         if (!page_close) {
             ++nk;
             fbase = cbase + (int64_t)ST * EVDR_TILE_PATCHES * EVDR_D;
@@ -729,7 +730,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             ++npgi;
             if (npgi < npages) {
                 npf = apf;
-                if (npgi + 1 < npages) apf = pageflags_c[pg0 + npgi + 1];
+                load_apf = npgi + 1 < npages;           // (issued behind the hand-over below: its lgkmcnt(0) would expose the latency)
                 int khi2, tlo, thi;
                 page_span(npf, nk, khi2, tlo, thi);
                 fbase = stage_base(npgi, nk);
@@ -790,6 +791,9 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             // stage hand-over (ring_barrier, maxsim_device.h): this wave's pieces of the stage have landed and every ds_read it
             // has issued is retired BEFORE it arrives; nothing can be scheduled into or across the statement
             ring_barrier<0>();
+            // the flag word of the page after the fetch cursor's: a scalar load with a whole stage to land in (the next hand-over
+            // retires it; the value is first used when the fetch cursor opens that page)
+            if (load_apf) apf = pageflags_c[pg0 + npgi + 1];
             if constexpr (DIAG) { const unsigned long long t = stamp(); d_bar += t - d_a; d_a = t; }
             if (refill && !spread) {
                 if (next_rows) {                                        // no row of the stage needs clamping: constant offsets

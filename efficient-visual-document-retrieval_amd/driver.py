@@ -84,21 +84,27 @@ def train_one_step(Qb, qmb, teacher, pmask_teacher, Pbar_param, pmask_student, o
     return float(loss.item())
 
 
-_EVAL_INDEX: list = []          # [(relevant_docs, docidx_2_docid, qsidx_2_query, nq, n, k_values, EvalIndex)], newest last
+_EVAL_INDEX: list = []          # [(relevant_docs, docidx_2_docid, qsidx_2_query, nq, n, k_values, EvalIndex, content stamp)], newest last
 
 
 def eval_index(evaluator: CustomRetrievalEvaluator, relevant_docs, docidx_2_docid, qsidx_2_query, nq: int, n: int) -> EvalIndex:
     """The lookup tables of one evaluation set (docid ranks for trec_eval's tie rule, judged pairs, ideal gains), built on
     the first evaluation and reused while the SAME qrels / id-map objects come back (they are constant over a run: the
     reference rebuilds its results dict from them on every evaluation, mainv2_iter_distill_infonce.py:311-317)."""
+    # identity of the three containers + a content stamp (sizes, number of judged pairs, first and last id of the map): a
+    # dict that is refilled or grows in place is noticed; one whose entries are OVERWRITTEN in place between evaluations with
+    # all counts unchanged is not -- treat the qrels / id maps of a run as immutable (the reference's are: loaded once from the npz)
     ks = tuple(evaluator.k_values)
+    stamp = (len(relevant_docs), sum(len(v) for v in relevant_docs.values()), len(docidx_2_docid),
+             docidx_2_docid.get("0") if n else None, docidx_2_docid.get(str(n - 1)) if n else None,
+             len(qsidx_2_query) if qsidx_2_query is not None else -1)
     for ent in _EVAL_INDEX:
-        if ent[0] is relevant_docs and ent[1] is docidx_2_docid and ent[2] is qsidx_2_query and ent[3:6] == (nq, n, ks):
+        if ent[0] is relevant_docs and ent[1] is docidx_2_docid and ent[2] is qsidx_2_query and ent[3:6] == (nq, n, ks) and ent[7] == stamp:
             return ent[6]
     qkeys = [str(qsidx_2_query[i]) if qsidx_2_query is not None else str(i) for i in range(nq)]
     docids = [docidx_2_docid[str(j)] for j in range(n)]
     index = EvalIndex(relevant_docs, qkeys, docids, ks)
-    _EVAL_INDEX.append((relevant_docs, docidx_2_docid, qsidx_2_query, nq, n, ks, index))
+    _EVAL_INDEX.append((relevant_docs, docidx_2_docid, qsidx_2_query, nq, n, ks, index, stamp))
     del _EVAL_INDEX[:-4]
     return index
 
@@ -167,7 +173,15 @@ def evaluation_loss(Q_test_norm, qmask_test, teacher, pmask_teacher, Pbar_param,
     of the same pages: the same kernel on the same inputs).  `teacher_cache` (a dict the caller keeps per dataset): the teacher's
     scores of the test queries are computed on the first evaluation and reused -- teacher and test queries never change
     (the reference recomputes both matrices on every evaluation; same numbers)."""
-    sc_t = teacher_cache.get("sc_t") if teacher_cache is not None else None
+    # what the cached teacher scores belong to: these test queries (tensor identity + version), this mask, this teacher, this
+    # sharding -- a dict reused for another dataset or teacher of the same shape recomputes instead of returning stale scores
+    from .evaluator.retrieval import _tensor_key
+    owner = (_tensor_key(Q_test_norm), _tensor_key(qmask_test),
+             id(teacher) if isinstance(teacher, TeacherScorer) else _tensor_key(teacher), _tensor_key(pmask_teacher),
+             tuple(shard_sizes) if shard_sizes is not None else None)
+    sc_t = None
+    if teacher_cache is not None and teacher_cache.get("owner") == owner:
+        sc_t = teacher_cache.get("sc_t")
     if sc_t is None:
         if isinstance(teacher, TeacherScorer):
             sc_t = teacher.scores(Q_test_norm, qmask_test)
@@ -176,7 +190,7 @@ def evaluation_loss(Q_test_norm, qmask_test, teacher, pmask_teacher, Pbar_param,
         if shard_sizes is not None:
             sc_t = gather_columns(sc_t, tuple(shard_sizes))
         if teacher_cache is not None:
-            teacher_cache["sc_t"] = sc_t
+            teacher_cache["sc_t"], teacher_cache["owner"] = sc_t, owner
     if sc_s is None:
         Psb = l2_normalize(Pbar_param * pmask_student.unsqueeze(-1))
         sc_s = score_multi_vector_masked(Q_test_norm, Psb, qmask_test, pmask_student, chunk_p=chunk_p)

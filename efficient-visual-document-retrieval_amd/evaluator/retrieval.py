@@ -57,20 +57,24 @@ def _tensor_key(t: Optional[torch.Tensor]):
 
 
 def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
-    """(planes, amax, tilemask, pageflags) of frozen fp32-like pages, from the cache when P and pmask are unchanged."""
+    """(planes, amax, tilemask, pageflags) of frozen fp32-like pages, from the cache when P and pmask are unchanged.
+    P is the CALLER's tensor (the cache is keyed on it and dies with it); embeddings narrower than 128 are padded here, on
+    a miss only -- keyed on a padded temporary, every call would redo pad + split + mask packing + the non-finite scan and push a
+    live entry out of the small LRU."""
     key = (_tensor_key(P), _tensor_key(pmask))
     hit = _PREPARED.get(key)
     if hit is not None and hit[0]() is not None and (pmask is None or hit[1]() is not None):
         _PREPARED.move_to_end(key)
         return hit[2]
-    if P.dtype == torch.bfloat16:                      # scored as they are: only the packed masks and the non-finite scan are kept
-        planes, amax = P.contiguous()[None], None
+    Pw = ops.pad_width(P)
+    if Pw.dtype == torch.bfloat16:                     # scored as they are: only the packed masks and the non-finite scan are kept
+        planes, amax = Pw.contiguous()[None], None
     else:
-        planes, amax = ops.split_f32(P)
+        planes, amax = ops.split_f32(Pw)
     tilemask, pageflags = ops.pack_pmask(pmask, P.shape[0], P.shape[1], P.device)
     ops.flag_nonfinite(planes[0], pmask, pageflags)
     prep = (planes, amax, tilemask, pageflags)
-    nbytes = 0 if (P.dtype == torch.bfloat16 and P.is_contiguous()) else planes.numel() * planes.element_size()
+    nbytes = 0 if (Pw is P and P.dtype == torch.bfloat16 and P.is_contiguous()) else planes.numel() * planes.element_size()
     if nbytes <= _PREPARED_MAX_BYTES:
         drop = lambda _ref, key=key: _PREPARED.pop(key, None)          # the tensor died: free its planes right away
         _PREPARED[key] = (weakref.ref(P, drop), weakref.ref(pmask, drop) if pmask is not None else None, prep, nbytes)
@@ -87,6 +91,7 @@ class _MaxSimMasked(torch.autograd.Function):
     def forward(ctx, Q, P, qmask, pmask):
         need_dq, need_dp = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         ctx.width = int(Q.shape[-1]) if Q.dim() == 3 else ops.D
+        P_caller = P                                      # what the prepared-pages cache is keyed on
         if Q.dim() == 3 and P.dim() == 3 and Q.shape[-1] == P.shape[-1] and 0 < Q.shape[-1] < ops.D:
             Q, P = ops.pad_width(Q), ops.pad_width(P)     # narrower embeddings ride on zero columns (exact); gradients are cut back
         both_bf16 = P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16
@@ -96,7 +101,7 @@ class _MaxSimMasked(torch.autograd.Function):
                   and Q.shape[0] > 0 and Q.shape[1] > 0 and P.shape[1] <= 65535 and Q.shape[1] <= 65535)
         if frozen:
             # frozen pages: mask packing, the non-finite scan and (fp32) the plane split are done once per tensor
-            planes, amax, tilemask, pageflags = _prepared_pages(P, pmask)
+            planes, amax, tilemask, pageflags = _prepared_pages(P_caller, pmask)
             qplanes, qamax = (Q.contiguous()[None], None) if both_bf16 else ops.split_f32(Q)
             out, arg = ops.maxsim_forward_prepared(qplanes, qamax, planes, amax, qmask, tilemask, pageflags,
                                                    want_argmax=need_dq)

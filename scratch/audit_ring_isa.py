@@ -97,7 +97,7 @@ def audit(name, body):
                 continue
             blk = [ins[q][0] for q in range(max(0, k - 4), k) if ins[q][2] == aid]
             nop = next((int(b.split()[1]) for b in reversed(blk) if b.startswith("s_nop")), None)
-            has_m0 = any(re.match(r"s_mov_b32 m0, s\d+", b) for b in blk)
+            has_m0 = any(re.match(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$", b) for b in blk)       # (vcc halves are SGPRs: the allocator may hand them out)
             sgpr_base = re.search(r", s\[\d+:\d+\]", t) is not None
             if not has_m0 or nop is None or (sgpr_base and nop < 4):
                 errs.append(f"B: LDS-DMA '{t}' without m0 write / wait states in its statement ({blk})")

@@ -312,3 +312,63 @@ def test_dq_is_deterministic_and_matches_the_oracle():
     runs = [ops.maxsim_backward_q(up.to(DEV), P.to(DEV), qm.to(DEV), pm.to(DEV), arg, nq, lq).cpu() for _ in range(3)]
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
     np.testing.assert_allclose(runs[0].numpy(), Qo.grad.numpy(), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("hot", [0.0, 0.35, 1.0])
+def test_dp_is_bit_reproducible_and_matches_the_oracle(hot):
+    """dP (evdr_maxsim_bwd) and the fused update (evdr_maxsim_bwd_adamw) give the same bits launch after launch, as the
+    reference's CPU backward does (autograd of evaluator/retrieval.py:201): inside a dP row the (query, token) terms are added
+    in ascending pair order, and a row shared between gather groups in group order.  hot = share of the pages' arg-max
+    mass planted on ONE patch (0.35: a salient patch heavier than a gather slice -> the ordered rounds; 1.0: every pair on
+    one row -> a chain of 32 groups); the launches are interleaved with an unrelated kernel so that timing differs."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(23)
+    nq, lq, npg, lp = 32, 32, 96, 206
+    Q = torch.nn.functional.normalize(torch.randn(nq, lq, 128, generator=g), dim=-1)
+    P = torch.nn.functional.normalize(torch.randn(npg, lp, 128, generator=g), dim=-1)
+    if hot > 0:                                   # patch 17 of every page close to a share `hot` of the query tokens
+        pick = torch.rand(nq, lq, generator=g) < hot
+        mean_tok = torch.nn.functional.normalize(Q[pick].mean(dim=0), dim=-1) if hot < 1.0 else None
+        if hot < 1.0:
+            Q[pick] = torch.nn.functional.normalize(Q[pick] * 0.3 + mean_tok, dim=-1)
+            P[:, 17] = mean_tok
+        else:
+            Q[:] = torch.nn.functional.normalize(torch.randn(128, generator=g), dim=-1) + 0.01 * Q
+            Q = torch.nn.functional.normalize(Q, dim=-1)
+            P[:, 17] = Q[0, 0]
+    qm = torch.rand(nq, lq, generator=g) > 0.1
+    pm = torch.rand(npg, lp, generator=g) > 0.05
+    up = torch.randn(nq, npg, generator=g)
+    Po = P.clone().requires_grad_(True)
+    O.maxsim_masked(Q, Po, qm, pm).backward(up)
+    Qd, Pd, qmd, pmd, upd = Q.to(DEV), P.to(DEV), qm.to(DEV), pm.to(DEV), up.to(DEV)
+    s, arg = ops.maxsim_forward(Qd, Pd, qmd, pmd, want_argmax=True)
+    if hot >= 0.35:
+        share = (arg.long() == 17).float().mean().item()
+        assert share > 0.25 * hot, f"the planted patch takes only {share:.2f} of the arg-max"
+    noise = torch.randn(1 << 22, device=DEV)
+    runs = []
+    for rep in range(6):
+        if rep % 2:
+            noise = noise * 1.0001 + 0.1           # an unrelated kernel in front: the backward starts on a busy chip
+        runs.append(ops.maxsim_backward(upd, Qd, qmd, pmd, arg, npg, lp))
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0])
+    np.testing.assert_allclose(runs[0].cpu().numpy(), Po.grad.numpy(), atol=2e-5, rtol=1e-5)
+    # the fused update: parameter and both moments, bit for bit, from identical starting states
+    lib = L.load()
+    outs = []
+    for rep in range(4):
+        x = P.to(DEV).clone()
+        ea = torch.zeros_like(x)
+        es = torch.zeros_like(x)
+        if rep % 2:
+            noise = noise * 0.9999 - 0.1
+        with L.on(DEV):
+            L.check(lib.evdr_maxsim_bwd_adamw(L.ptr(upd.contiguous()), L.ptr(Qd.contiguous()), L.ptr(qmd.contiguous()),
+                                              L.ptr(pmd.contiguous()), L.ptr(arg), L.ptr(x), L.ptr(ea), L.ptr(es), nq, lq, npg, lp, 128,
+                                              1e-3, 0.9, 0.999, 1e-8, 1e-2, 1, 1e-12, None, L.current_stream_handle(DEV)))
+        outs.append((x, ea, es))
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))

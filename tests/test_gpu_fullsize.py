@@ -105,6 +105,12 @@ def test_config2_full_vidore_size_properties(dev):
     assert torch.equal(s1.gather(1, ti.long()), ts)
     ws, wi = O.topk_rows(s1.cpu(), k)
     assert torch.equal(ti.cpu(), wi)
+    corpus.score_events = []                                             # bench.py's bracketed form of the same step: same bits
+    ts_b, ti_b = corpus.topk(Q, None, k)
+    assert len(corpus.score_events) == 1 and torch.equal(ts_b, ts) and torch.equal(ti_b, ti)
+    torch.cuda.synchronize()
+    assert corpus.score_events[0][0].elapsed_time(corpus.score_events[0][1]) > 0
+    corpus.score_events = None
     msgs = []
     for r in range(3):
         lo, hi = shard_range(n, r, 3)

@@ -197,7 +197,15 @@ def test_prepared_pages_cache(dev, ER):
     Qc = Q.cpu().clone().requires_grad_(True)
     O.maxsim_masked(Qc, P.cpu(), qm.cpu(), pm.cpu()).sum().backward()
     np.testing.assert_allclose(Qg.grad.cpu().numpy(), Qc.grad.numpy(), atol=2e-5, rtol=1e-5)
-    del P, a, b, c, d
+    # embeddings narrower than 128 are padded INSIDE the cache (keyed on the caller's tensor): a second call hits
+    ER.forget_prepared()
+    Pn, Qn = P[..., :48].contiguous(), Q[..., :48].contiguous()
+    e1 = ER.score_multi_vector_masked(Qn, Pn, qm, pm)
+    assert len(ER._PREPARED) == 1 and next(iter(ER._PREPARED.values()))[0]().data_ptr() == Pn.data_ptr()      # the 48-wide tensor itself
+    e2 = ER.score_multi_vector_masked(Qn, Pn, qm, pm)
+    assert len(ER._PREPARED) == 1 and torch.equal(e1, e2)
+    np.testing.assert_allclose(e1.cpu().numpy(), O.maxsim_masked(Qn.cpu(), Pn.cpu(), qm.cpu(), pm.cpu()).numpy(), atol=SCORE_ATOL)
+    del P, a, b, c, d, Pn, e1, e2
     import gc
     gc.collect()
     assert all(e[0]() is not None for e in ER._PREPARED.values())         # entries of dead tensors are dropped at once
@@ -540,6 +548,47 @@ def test_stream_adamw_equals_torch_adamw(dev, shape):
     d.grad = torch.ones_like(d)
     od.step()
     assert torch.isfinite(d).all() and not torch.equal(d.detach(), x0)
+
+
+def test_stream_adamw_takes_torchs_step_whole_when_anything_is_ineligible(dev):
+    """eligibility is decided before anything is touched.  A parameter that is a view at an odd storage offset
+    (not 16-byte aligned), a gradient that is not dense, or moments restored onto another device make the WHOLE step torch's
+    own -- bit-equal to torch.optim.AdamW, step counters in step -- instead of failing after some parameters were updated."""
+    from evdr_amd.utils.utils import StreamAdamW
+    gen = torch.Generator().manual_seed(77)
+    base = torch.randn(4 * 33 + 1, generator=gen).to(dev)
+    good0, odd0 = torch.randn(64, 128, generator=gen).to(dev), base[1:].view(4, 33)        # odd0: data_ptr % 16 == 4
+    assert odd0.data_ptr() % 16 != 0
+
+    def pair(cls):
+        a, b = torch.nn.Parameter(good0.clone()), torch.nn.Parameter(base.clone()[1:].view(4, 33))
+        return a, b, cls([a, b], lr=1e-3, weight_decay=1e-2)
+    a1, b1, o1 = pair(StreamAdamW)
+    a2, b2, o2 = pair(torch.optim.AdamW)
+    assert b1.data_ptr() % 16 != 0
+    for i in range(3):
+        ga, gb = torch.randn(64, 128, generator=gen).to(dev), torch.randn(4, 33, generator=gen).to(dev)
+        a1.grad, b1.grad, a2.grad, b2.grad = ga.clone(), gb.clone(), ga.clone(), gb.clone()
+        o1.step()
+        o2.step()
+        assert torch.equal(a1, a2) and torch.equal(b1, b2)                                  # torch's rule for BOTH parameters
+        assert float(o1.state[a1]["step"]) == float(o1.state[b1]["step"]) == i + 1
+    # a non-dense gradient: torch's step again
+    a3 = torch.nn.Parameter(good0.clone())
+    a4 = torch.nn.Parameter(good0.clone())
+    o3, o4 = StreamAdamW([a3], lr=1e-3), torch.optim.AdamW([a4], lr=1e-3)
+    g = torch.randn(128, 64, generator=gen).to(dev).t()
+    a3.grad, a4.grad = g, g.clone(memory_format=torch.preserve_format)
+    o3.step()
+    o4.step()
+    assert torch.equal(a3, a4)
+    # moments restored as CPU tensors (a state dict loaded by hand): the kernel path must not be entered
+    a5 = torch.nn.Parameter(good0.clone())
+    o5 = StreamAdamW([a5], lr=1e-3)
+    a5.grad = torch.ones_like(a5)
+    o5.step()
+    o5.state[a5]["exp_avg"] = o5.state[a5]["exp_avg"].cpu()
+    assert not o5._eligible(a5)
 
 
 def test_a6_full_gradient_identical_inputs(dev, ER):
