@@ -19,6 +19,10 @@ SOURCES = ["maxsim_fwd.hip", "maxsim_fwd16.hip", "maxsim_bwd.hip", "topk.hip", "
 HEADERS = [os.path.join(CSRC, "evdr_common.h"), os.path.join(CSRC, "maxsim_device.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "evdr.h")]
 # -fno-honor-nans: lets fmaxf chains fold to v_max3_f32 without canonicalising moves (infinities are kept)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fno-honor-nans", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-source extras.  maxsim_fwd16.hip: MFMA destinations stay in VGPRs also in a kernel that uses AGPRs (the eight-queries-per-wave
+# instance keeps its query fragments there): LLVM otherwise switches such a kernel to the AGPR-destination form and reads every
+# accumulator back with v_accvgpr_read; every other instance compiles to the same instructions with or without the option
+EXTRA_FLAGS = {"maxsim_fwd16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -59,7 +63,7 @@ def build(force: bool = False, verbose: bool = True, experiment: bool = False, s
 
     def compile_one(job):
         sp, obj = job
-        cmd = [hipcc] + flags + ["-c", sp, "-o", obj]
+        cmd = [hipcc] + flags + EXTRA_FLAGS.get(os.path.basename(sp), []) + ["-c", sp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}")

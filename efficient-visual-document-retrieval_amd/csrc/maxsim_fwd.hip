@@ -71,6 +71,12 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
             waves = 4;
             qw = (p.nq + 3) / 4;
         }
+#ifdef EVDR_EXPERIMENT
+        if (variant == 60 && qw == 4 && p.ntiles >= 8 && !p.per_token) {      // A/B: the same 32 queries per workgroup on four waves of eight
+            waves = 4;
+            qw = 8;
+        }
+#endif
     } else {
         qw = (p.nq > 8) ? 2 : 1;
     }

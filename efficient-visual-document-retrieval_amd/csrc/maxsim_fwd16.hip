@@ -551,10 +551,12 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     // pbase: first patch index of the 16-patch half (uniform); the lane's accumulator i is patch pbase + 4g + i
     auto chains_full = [&](const frag (&a)[NPL][4], int pbase) {           // all 16 patches of the half valid
         const int pb = pbase + 4 * g;
-        if constexpr (NPL == 1 && QW <= 2) {
+        if constexpr (NPL == 1 && (QW <= 2 || QW >= 8)) {
             // one or two queries per wave: the 2 QW chains of a half-tile are issued INTERLEAVED (k-step outermost), so that
             // consecutive MFMAs never depend on each other; with 8 chains (QW = 4) the other wave of the SIMD fills those
-            // slots and keeping one accumulator live at a time matters more (+4..5 % at 5-16 queries per launch)
+            // slots and keeping one accumulator live at a time matters more (+4..5 % at 5-16 queries per launch).
+            // QW = 8 (one wave per SIMD, experiment): nothing else fills a dependent chain's gaps, and the VGPR half has the
+            // room for 16 live accumulators
             f32x4v acc[QW][2];
 #pragma unroll
             for (int j = 0; j < QW; ++j) acc[j][0] = acc[j][1] = f32x4v{0, 0, 0, 0};
@@ -690,6 +692,20 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
 #pragma unroll
         for (int s = 0; s < 4; ++s) { c0 |= frag_exp_carry(bq[j][0][0][s]); c1 |= frag_exp_carry(bq[j][0][1][s]); }
         qbad[j] = token_bad_bits((c0 & 0x80008000u) != 0u, (c1 & 0x80008000u) != 0u);
+    }
+    if constexpr (QW >= 8) {
+        // one wave per SIMD, 512 registers: the 256 registers of query fragments are pinned to the AGPR half here -- an "a"-class
+        // value stays there, and v_mfma reads its B operand from AGPRs directly -- which leaves the whole VGPR half to the page
+        // fragments, accumulators and running maxima (left to itself the allocator put accumulators and page fragments into
+        // AGPRs and paid 5 444 v_accvgpr_read for 4 736 MFMAs)
+#pragma unroll
+        for (int j = 0; j < QW; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) asm volatile("" : "+a"(bq[j][pl][t][s4]));
     }
     if constexpr (DIAG) d_pro = stamp() - d_t0;
     const bool spread_ok = p.inblock_refill != 0;
@@ -1144,7 +1160,7 @@ hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC, WAVES, NT>;
     static uint64_t attr_devs = 0;
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
-    const int64_t blocks = evdr_set_geometry(p, WAVES * QW, WAVES == 4 ? 2 : 1);
+    const int64_t blocks = evdr_set_geometry(p, WAVES * QW, LDS <= 80 * 1024 ? 2 : 1);      // two workgroups share a CU's 160 KiB, or one owns it
     static const char* const name = [] {
         static char buf[96];
         snprintf(buf, sizeof(buf), "maxsim_fwd16s_kernel<%d,%d,%s,%d,%d,%s,%s,%d,%d,%s>", QW, NPL, ARGMAX ? "true" : "false", ST, NSTAGE,
@@ -1232,6 +1248,14 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, i
     }
 #endif
     if (geom == 2 && ntiles >= 8 && qw == 4) return launch16s<4, 1, false, 8, 2, false, false>(p, stream);   // A/B: no priority schedule
+#ifdef EVDR_EXPERIMENT
+    // variant 60 (experiment build only): 32 queries per workgroup as FOUR waves of eight -- one wave per SIMD with 512 registers,
+    // the query fragments pinned to the AGPR half and read from there by the MFMAs -- instead of eight waves of four: half the LDS
+    // fragment reads per FLOP.  Measured (profiles/r04_experiments.txt): bit-identical scores, 16 % SLOWER at 1024 x 20 000
+    // (111.8 ms against 96.5; 23 % slower with dependent chains): with one wave per SIMD nothing covers a wave's own waits
+    // (fragment reads, LDS-DMA issue, MFMA-result latency), and hipcc's schedule leaves those in the open.  Not shipped.
+    if (qw == 8 && waves == 4 && ntiles >= 8) return launch16s<8, 1, false, 8, 2, false, false, 1, 4>(p, stream);
+#endif
     // launches of ONE query group (<= 8 queries here): every page is read by exactly one workgroup, exactly once -> the corpus
     // stream uses the non-temporal policy (NT instances; geom 31 = A/B without it)
     const bool nt = geom != 31;

@@ -31,7 +31,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "efficient-visual-document-retrieval_amd", "csrc", "maxsim_fwd16.hip")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fno-honor-nans", "-std=c++17", "-S", "--cuda-device-only"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fno-honor-nans", "-std=c++17", "-S", "--cuda-device-only", "-mllvm", "-amdgpu-mfma-vgpr-form"]     # as build.py compiles this source
 
 
 def listing(extra):
@@ -102,7 +102,7 @@ def audit(name, body):
             if not has_m0 or nop is None or (sgpr_base and nop < 4):
                 errs.append(f"B: LDS-DMA '{t}' without m0 write / wait states in its statement ({blk})")
         elif op.startswith("scratch_"):
-            errs.append(f"C: scratch access '{t}'")
+            errs.append("C: scratch access (" + op + ")")
         elif op.startswith("v_permlane16_swap") or op.startswith("v_permlane32_swap"):
             ok = in_asm and k >= 2 and ins[k - 1][0] == "v_nop" and ins[k - 2][0] == "v_nop" and ins[k - 1][2] == aid and ins[k - 2][2] == aid
             if not ok:

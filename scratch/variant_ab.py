@@ -15,7 +15,9 @@ for rnd in range(rounds + 1):
         a.record(); corpus.score(Q, None, out=out); b.record(); torch.cuda.synchronize()
         if rnd == 0:
             if ref is None: ref = out.clone()
-            else: assert (out - ref).abs().max().item() < 1e-4
+            else:
+                d = (out - ref).abs().max().item(); print(f"  variant {v}: max |diff| vs variant {variants[0]} = {d:.3e} ({'bit-identical' if torch.equal(out, ref) else 'NOT bit-identical'}), kernel {lib.evdr_last_fwd_kernel().decode()}", flush=True)
+                assert d < 1e-4
         else: res[v].append(a.elapsed_time(b))
 lib.evdr_debug_set_fwd_variant(0)
 for v in variants:
