@@ -79,6 +79,9 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
 #endif
     } else {
         qw = (p.nq > 8) ? 2 : 1;
+#ifdef EVDR_EXPERIMENT
+        if (variant == 13) qw = 2;          // dispatched as one query per wave on 4-wave workgroups (see maxsim_fwd16.hip)
+#endif
     }
     // HBM-bound launches (a handful of queries) want the refill in flight as early as possible: +3 % at 1-4 queries;
     // everything else hides the refill's address work under MFMAs: +2..4 %

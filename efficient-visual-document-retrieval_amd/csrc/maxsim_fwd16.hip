@@ -1218,6 +1218,12 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, i
     }
 #endif
     if (nplanes == 2) {
+#ifdef EVDR_EXPERIMENT
+        // variant 12 (experiment build): the student forward as TWO independent 4-wave workgroups per CU (1-tile stages, 64 KiB of
+        // ring each) instead of one 8-wave workgroup -- VERDICT round 3, item 5 (profiles/r04_experiments.txt)
+        if (geom == 12 && want_argmax && qw == 2) return launch16s<2, 2, true, 1, 2, false, false, 2, 4>(p, stream);
+        if (geom == 13 && want_argmax && qw == 2) return launch16s<1, 2, true, 1, 2, false, false, 2, 4>(p, stream);
+#endif
         // 16-KiB tiles: 4-tile stages (2 x 5 x 16 KiB = all 160 KiB of LDS) or 3-tile stages, whichever sends fewer FULL tiles
         // through the per-tile path: a stage runs as the straight-line block only if all its tiles are full, and a lone
         // tail tile rides in the previous stage.  1030 patches = 33 tiles: 8 x 4 + tail; 206 patches = 7 tiles: 2 x 3 + tail

@@ -14,6 +14,13 @@
  *   - nothing here allocates, frees or synchronises: scratch memory comes in through
  *     `workspace` (query the size first), work is enqueued on `hip_stream` (a hipStream_t, may
  *     be NULL for the default stream) and the call returns immediately (graph-capture safe);
+ *   - THREADING: the library is meant to be driven by ONE host thread per process, as the reference drives its scorer (a single
+ *     Python thread, DataLoader(num_workers=0); mainv2_iter_distill_infonce.py:269-321).  Concurrent calls from several host
+ *     threads are not supported: the first launch of each kernel instance raises that kernel's dynamic-LDS limit and
+ *     remembers the device in an unsynchronised function-local static (csrc/maxsim_fwd16.hip: launch16s / launch16), and the
+ *     debug hooks below are process-wide.  Different STREAMS from that one thread are fine (nothing here synchronises), and
+ *     so are several processes per node (one per GPU: corpus.py / bench.py).  evdr_last_error() and evdr_last_fwd_kernel()
+ *     are thread-local only so that a host-side error text is never torn; that is not a threading guarantee for the launches;
  *   - D (embedding width) must be 128 (ColPali / ColQwen projection width);
  *   - masks are one byte per token, 0 = masked (torch.bool storage);
  *   - dtype: EVDR_F32 inputs are scored to fp32 accuracy (fp16 hi/lo planes of the power-of-two-scaled
