@@ -49,7 +49,7 @@ def gen_pages(lo: int, hi: int, dev) -> torch.Tensor:
     return out
 
 
-def make_queries(nq: int, n_pages: int, shard, lo: int, hi: int, dev, world: int, group=None):
+def make_queries(nq: int, n_pages: int, shard, lo: int, hi: int, dev, world: int, group=None, multi=None):
     """Planted queries: query i targets page t_i = (i*7919) mod N; token n = normalise(P[t_i, pi_i(n)]
     + 0.5 eps).  Each rank fills the queries whose target lives in its shard; an all-reduce (setup, untimed) sums."""
     import torch.distributed as dist
@@ -63,7 +63,7 @@ def make_queries(nq: int, n_pages: int, shard, lo: int, hi: int, dev, world: int
         t_local = (targets[mine] - lo).to(dev)
         base = shard[t_local[:, None], rows[mine].to(dev)].float()                          # (m, LQ, D)
         Q[mine.to(dev)] = torch.nn.functional.normalize(base + 0.5 * eps[mine].to(dev), dim=-1)
-    if world > 1:
+    if world > 1 or multi:
         if dist.get_backend(group) == "gloo":
             host = Q.cpu()
             dist.all_reduce(host, group=group)
@@ -231,6 +231,10 @@ def main():
                     help="skip the `train_step` (configs[4]) and `eval` (configs[1]) records that follow the timed region at N=1")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse N>1 on a 1-GPU box)")
+    ap.add_argument("--dist-at-one", action="store_true",
+                    help="with --gpus 1: still form the process groups (gloo control + RCCL data group of ONE rank) and run the barrier, "
+                         "the step-clock all-reduce and the candidate exchange of the phase breakdown -- a rehearsal of the N > 1 code path "
+                         "on a 1-GPU box; the timed step itself has nothing to exchange")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, form the process group, print its size and exit (launch check; no GPU work)")
     args = ap.parse_args()
@@ -243,6 +247,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size must equal --gpus")
     import torch.distributed as dist
+    multi = world > 1 or args.dist_at_one             # process groups exist (world 1 only as the --dist-at-one rehearsal)
+    if multi and world == 1 and "MASTER_ADDR" not in os.environ:
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC for RCCL; before the first HIP call
     launcher = os.environ.get("EVDR_BENCH_LAUNCHER", "torchrun" if "WORLD_SIZE" in os.environ else "none")
     if args.rendezvous_only:
@@ -268,7 +278,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     backend, fallback_reason, ranks_seen = args.backend, None, 1
     group = None                                      # the DATA group: candidates, score columns, barriers, the step clock
-    if world > 1:
+    if multi:
         import datetime
         # The default group is ALWAYS gloo: a control plane that needs no GPU and cannot fail the way a first RCCL run can.  The
         # data group (nccl = RCCL over xGMI) is formed next to it, and whether it is usable is AGREED over the control plane: every
@@ -311,7 +321,7 @@ def main():
     lo, hi = shard_range(args.pages, rank, world)
     shard_pages = gen_pages(lo, hi, dev)
     corpus = PageCorpus.from_tensor(shard_pages, None, idx_base=lo)
-    Q, targets = make_queries(args.queries, args.pages, shard_pages, lo, hi, dev, world, group)
+    Q, targets = make_queries(args.queries, args.pages, shard_pages, lo, hi, dev, world, group, multi)
     retriever = ShardedRetriever(corpus, group)
 
     def step():
@@ -324,7 +334,7 @@ def main():
             dist.barrier(group=group)
 
     def fence():
-        if world > 1:
+        if multi:
             barrier()
         torch.cuda.synchronize()
 
@@ -341,7 +351,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     step_events, corpus.score_events = corpus.score_events, None
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(tmax.item())
@@ -359,7 +369,7 @@ def main():
         """Control-plane agreement (gloo default group): True only if EVERY rank says ok -- taken before a section that holds
         collectives, so that a rank which failed locally makes all ranks skip it together instead of leaving its peers waiting
         in the collective for their timeout."""
-        if world == 1:
+        if not multi:
             return ok
         v = torch.tensor([1 if ok else 0], dtype=torch.int32)
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
@@ -389,7 +399,7 @@ def main():
                 err = ex
             if not all_ranks_ok(err is None):
                 raise err if err is not None else RuntimeError("a peer rank failed in the device phases")
-            if world > 1:
+            if multi:
                 barrier()
                 torch.cuda.synchronize()
                 th = time.perf_counter()
@@ -403,10 +413,10 @@ def main():
                 acc[3] += e[3].elapsed_time(e[4])
         mine = torch.tensor([a / reps for a in acc], dtype=torch.float64)
         worst = mine.clone()
-        if world > 1:
+        if multi:
             dist.all_reduce(worst, op=dist.ReduceOp.MAX)          # control plane (host tensor)
         names = ("score_ms", "topk_ms", "exchange_ms", "merge_ms")
-        keep = 4 if world > 1 else 2
+        keep = 4 if multi else 2
         return {"rank0": {n: float(v) for n, v in zip(names[:keep], mine[:keep])},
                 "max_over_ranks": {n: float(v) for n, v in zip(names[:keep], worst[:keep])},
                 "note": "separate instrumented passes after the timed region (score and top-k as two calls), mean of %d" % reps}
@@ -513,11 +523,11 @@ def main():
                        "pages": args.pages, "patches_per_page": LP, "dim": D, "queries_per_step": args.queries,
                        "query_tokens": LQ, "topk": args.topk, "parallelism": f"page-shard x{world}"},
             "queries_per_sec": args.queries / (ms_per_step * 1e-3), "ndcg_at_5": ndcg5,
-            "dist": {"world_size": dist.get_world_size() if world > 1 else 1, "ranks_seen": ranks_seen,
-                     "backend": dist.get_backend(group) if world > 1 else None, "control_backend": "gloo" if world > 1 else None,
-                     "backend_requested": args.backend if world > 1 else None,
+            "dist": {"world_size": dist.get_world_size() if multi else 1, "ranks_seen": ranks_seen,
+                     "backend": dist.get_backend(group) if multi else None, "control_backend": "gloo" if multi else None,
+                     "backend_requested": args.backend if multi else None,
                      "backend_fallback_reason": fallback_reason, "launcher": launcher,
-                     "exchange": "all_gather_into_tensor of (nq, 2k) int32 per rank" if world > 1 else None,
+                     "exchange": "all_gather_into_tensor of (nq, 2k) int32 per rank" if multi else None,
                      "pages_per_rank": corpus.n_pages},
             "phases": phases,
             "roofline": roofline, "cpu_baseline": cpu_base,
@@ -525,7 +535,7 @@ def main():
             "device_errors_after_timed_region": device_errors or None,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()                                 # control plane: leaves together whatever happened to the data group
         dist.destroy_process_group()
     if device_errors:

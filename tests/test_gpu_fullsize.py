@@ -295,3 +295,24 @@ def test_kernel_rate_floors(dev):
     ms32 = best_ms(lambda: ops.maxsim_forward_prepared(qp, qa, c32.planes, c32.amax, None, c32.tilemask, c32.pageflags, out=o32))
     tf32 = 512 * 2000 * 2 * LQ * LP * D * 3 / ms32 / 1e9
     assert tf32 > 1000, f"fp32 (fp16 hi/lo) MaxSim kernel at {tf32:.0f} TFLOP/s of plane products"
+
+
+def test_bench_forms_its_rccl_data_group_with_one_rank():
+    """`bench.py --dist-at-one`: the N > 1 code path of the bench (gloo control group, RCCL data group formed beside it and agreed
+    over the control plane, barrier on the data group, step-clock all-reduce, candidate all-gather + merge in the phase breakdown)
+    with the one rank a 1-GPU box has -- the success path of the group formation, which the 2-rank rehearsals (gloo; RCCL refusing
+    a shared GPU) do not reach."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dist-at-one", "--pages", "3000", "--queries", "64", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-other-regimes"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    d = line["dist"]
+    assert d["backend"] == "nccl" and d["control_backend"] == "gloo" and d["backend_fallback_reason"] is None and d["ranks_seen"] == 1
+    assert set(line["phases"]["rank0"]) == {"score_ms", "topk_ms", "exchange_ms", "merge_ms"} and line["ndcg_at_5"] == 1.0
+    assert line["device_errors_after_timed_region"] is None
