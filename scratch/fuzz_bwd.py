@@ -3,6 +3,8 @@ GPU: random page counts / lengths (both sides of the 128-row slab and of the 102
 usage: python scratch/fuzz_bwd.py <first_seed> <count> [long]     (long, round 3: page lengths 1030 ... 65535, few pages)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); import evdr_amd
+from evdr_amd import _lib as _L
+if os.environ.get("EVDR_FUZZ_LIB"): _L.LIB_PATH = os.path.join(_L.PKG_DIR, os.environ["EVDR_FUZZ_LIB"])     # e.g. libevdr_sentinel.so (scratch-only switch)
 from evdr_amd import ops
 dev = torch.device("cuda:0"); s0, n = int(sys.argv[1]), int(sys.argv[2]); bad = 0
 LONG = len(sys.argv) > 3 and sys.argv[3] == "long"
@@ -27,6 +29,8 @@ for seed in range(s0, s0 + n):
     want.view(-1, 128).index_add_(0, idx, (w[..., None].double() * Q[:, None, :, :].double()).reshape(-1, 128))
     got = ops.maxsim_backward(gr, Q, qm, pm, arg16, npg, lp)
     e1 = (got.double() - want).abs().max().item()
+    again = ops.maxsim_backward(gr, Q, qm, pm, arg16, npg, lp)                              # round 4: bit-reproducible
+    if not torch.equal(got, again): e1 = float("inf")
     tol = 1e-5 * max(1.0, want.abs().max().item())
     # fused update with planes == unfused pieces: l2norm backward of `want` + torch AdamW formula, and planes == l2norm_split(x_new)
     x = (torch.randn(npg, lp, 128, generator=g) * 0.5).to(dev) * pm.unsqueeze(-1)

@@ -6,6 +6,8 @@ import os, sys, numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import evdr_amd
+from evdr_amd import _lib as _L
+if os.environ.get("EVDR_FUZZ_LIB"): _L.LIB_PATH = os.path.join(_L.PKG_DIR, os.environ["EVDR_FUZZ_LIB"])     # e.g. libevdr_sentinel.so (scratch-only switch)
 from evdr_amd import ops
 from oracle import maxsim_oracle as O
 import test_gpu_random_sweep as T
