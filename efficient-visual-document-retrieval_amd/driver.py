@@ -504,6 +504,7 @@ class FusedStudent:
         # for the tensor object and version of x recorded in _planes_of (any torch in-place write to x invalidates them)
         self._planes = None
         self._planes_of = None
+        self.direct_loss_store = True   # update(..., loss_to_host=True): the loss kernel writes the pinned host word itself (False: a copy launch, for the A/B)
         self._loss_host = None          # pinned scalar + event of update(..., loss_to_host=True)
         self._loss_event = None
         self._loss_ws: Dict[int, torch.Tensor] = {}     # batch size -> workspace of the one-launch loss, owned by this student
@@ -562,12 +563,17 @@ class FusedStudent:
         (`wait_loss()` returns it as soon as that copy has landed, while the update still runs).  `scored` = (scores,
         argmax) of `self.scores(Qb, qmb)` when the caller has issued the student forward already (on another stream)."""
         sc_s, arg = scored if scored is not None else self.scores(Qb, qmb, qplanes)
-        loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True, ws=self.loss_workspace(sc_s.shape[0]))
+        if loss_to_host and self._loss_host is None:
+            self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
+            self._loss_event = torch.cuda.Event()
+        # loss_to_host: the loss kernel stores its scalar straight into the pinned host word (device-accessible memory): no copy
+        # launch between the loss and the update (4.4 us of kernel + a launch gap per step), only the event
+        direct = loss_to_host and self.direct_loss_store
+        loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True, ws=self.loss_workspace(sc_s.shape[0]),
+                                           loss_out=self._loss_host if direct else None)
         if loss_to_host:
-            if self._loss_host is None:
-                self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
-                self._loss_event = torch.cuda.Event()
-            self._loss_host.copy_(loss, non_blocking=True)
+            if not direct:
+                self._loss_host.copy_(loss, non_blocking=True)
             self._loss_event.record()
         self.apply(dscore, Qb, qmb, arg, state)
         return loss

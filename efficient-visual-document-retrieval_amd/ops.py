@@ -278,11 +278,15 @@ def infonce_workspace(b: int, dev) -> torch.Tensor:
 
 
 def infonce_distill(score_s: torch.Tensor, score_t: torch.Tensor, temperature: float,
-                    want_grad: bool, ws: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                    want_grad: bool, ws: Optional[torch.Tensor] = None,
+                    loss_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """A5 (criterion.py:56-68) + its closed-form gradient in one pass.  Without `ws`: the stateless two-launch form (row
     kernel + mean kernel, scratch allocated per call).  With `ws` = `infonce_workspace(b, dev)` owned by the caller: ONE
     launch (the last workgroup reduces the row losses; same bits) -- the workspace carries a ticket word between calls, so
-    it belongs to exactly one issuer."""
+    it belongs to exactly one issuer.
+    `loss_out`: where the scalar goes -- an fp32 scalar on the device, or a PINNED host scalar (hipHostMalloc memory is
+    device-accessible under the same address: the kernel's one 4-byte store lands in host memory and a caller that wants
+    float(loss) needs no device-to-host copy launch, only an event behind this kernel)."""
     dev = _require_cuda(score_s, score_t)
     if score_s.shape != score_t.shape or score_s.dim() != 2:
         raise RuntimeError("score_s and score_t must be (B, N) and equal-shaped")
@@ -290,7 +294,13 @@ def infonce_distill(score_s: torch.Tensor, score_t: torch.Tensor, temperature: f
     lib = L.load()
     ss = score_s.float().contiguous()
     st = score_t.float().contiguous()
-    loss = torch.empty((), dtype=torch.float32, device=dev)
+    if loss_out is None:
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+    else:
+        ok = loss_out.dtype == torch.float32 and loss_out.numel() == 1 and (loss_out.device == dev or (not loss_out.is_cuda and loss_out.is_pinned()))
+        if not ok:
+            raise RuntimeError("infonce_distill: `loss_out` must be one fp32 element on the scores' device or in pinned host memory")
+        loss = loss_out
     grad = torch.empty_like(ss) if want_grad else None
     stream = L.current_stream_handle(dev)
     if ws is None:

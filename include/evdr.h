@@ -235,7 +235,9 @@ int evdr_maxsim_topk(const uint16_t* Qplanes, const uint16_t* Pplanes,
 /* ---- A5 (+ its gradient): infonce_distillation_loss (criterion.py:56-68) -----------------------------
  * loss = mean_b CE(score_s[b,:]/temperature, argmax_p score_t[b,:]);
  * dscore[b,p] = (softmax(score_s[b,:]/temperature)[p] - [p == target_b]) / (temperature * B).
- * score_s/score_t (b, n) fp32 dense; loss: 1 float (device); dscore_or_null (b, n);
+ * score_s/score_t (b, n) fp32 dense; loss: 1 float -- device memory, or device-accessible pinned host memory (hipHostMalloc:
+ * the one 4-byte store then lands on the host and float(loss) needs no copy launch, only an event behind the call);
+ * dscore_or_null (b, n);
  * row_loss: b floats of scratch (device). */
 int evdr_infonce_distill_fwd_bwd(const float* score_s, const float* score_t, int64_t b, int64_t n,
                                  float temperature, float* loss, float* dscore_or_null,
