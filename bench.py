@@ -528,7 +528,9 @@ def main():
                      "backend_requested": args.backend if multi else None,
                      "backend_fallback_reason": fallback_reason, "launcher": launcher,
                      "exchange": "all_gather_into_tensor of (nq, 2k) int32 per rank" if multi else None,
-                     "pages_per_rank": corpus.n_pages},
+                     "pages_per_rank": corpus.n_pages,
+                     "rehearsal": "--dist-at-one: groups, barrier, clock all-reduce and the phase breakdown's exchange with ONE rank; "
+                                  "the timed step had nothing to exchange" if (multi and world == 1) else None},
             "phases": phases,
             "roofline": roofline, "cpu_baseline": cpu_base,
             "train_step": train_step, "eval": eval_rec,
