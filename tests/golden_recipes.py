@@ -185,3 +185,24 @@ def v3_case():
           "lambda_mixed": 0.5, "mixup_alpha": 0.4, "mixup_seed": 78,
           "lambda_aux": 0.3, "aux_docs": 3}
     return Qb, qmb, Pt, pmt, Pbar0, pms, hp
+
+
+def config1_case():
+    """BASELINE.json configs[1] at its FULL size (docvqa_test_subsampled shape: 500 queries x 500 pages x 1030 patches, D = 128),
+    synthetic as SURVEY §8(d) defines it: query i is planted on page t_i = (i * 7919) mod 500 (token n = normalise(P[t_i, pi_i(n)]
+    + 0.5 eps)), ragged valid page lengths 700..1030, the last 0..12 tokens of a query masked.  Values are bf16-representable, so
+    the ONE fixture made from them by the reference's fp32 scorer serves the bf16 kernel and the fp32 (fp16 hi/lo) kernel alike.
+    -> Q (500,32,128), P (500,1030,128), qmask, pmask, targets (500,)"""
+    gen = torch.Generator().manual_seed(20261004)
+    n, nq, lp, lq = 500, 500, 1030, 32
+    P = _bf16r(_unit(gen, n, lp, 128))
+    lens = torch.randint(700, lp + 1, (n,), generator=gen)
+    pm = torch.arange(lp)[None, :] < lens[:, None]
+    targets = (torch.arange(nq) * 7919) % n
+    rows = torch.stack([torch.randperm(700, generator=gen)[:lq] for _ in range(nq)])       # valid rows of every page
+    eps = _unit(gen, nq, lq, 128)
+    Q = _bf16r(F.normalize(P[targets[:, None], rows] + 0.5 * eps, dim=-1))
+    qm = torch.ones(nq, lq, dtype=torch.bool)
+    cut = lq - torch.randint(0, 13, (nq,), generator=gen)
+    qm[torch.arange(lq)[None, :] >= cut[:, None]] = False
+    return Q, P, qm, pm, targets

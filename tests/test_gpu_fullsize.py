@@ -316,3 +316,33 @@ def test_bench_forms_its_rccl_data_group_with_one_rank():
     assert d["backend"] == "nccl" and d["control_backend"] == "gloo" and d["backend_fallback_reason"] is None and d["ranks_seen"] == 1
     assert set(line["phases"]["rank0"]) == {"score_ms", "topk_ms", "exchange_ms", "merge_ms"} and line["ndcg_at_5"] == 1.0
     assert line["device_errors_after_timed_region"] is None
+
+
+def test_config1_full_size_against_the_reference_itself(dev, golden):
+    """BASELINE.json configs[1] at its FULL size (500 queries x 500 pages x 1030 patches, ragged pages, masked query tails) against
+    scores the REFERENCE's own `score_multi_vector_masked` produced for the same seeded inputs (tests/golden/config1_full.npz,
+    made by tests/golden/make_golden_config1.py): every one of the 250 000 scores within 1e-4 on the bf16 kernel and on the fp32
+    (fp16 hi/lo) kernel, top-100 indices identical wherever the reference's own ranking gap exceeds 2e-4, and nDCG@5 / Recall@1 of
+    the device pipeline (`driver.eval_retrieval`) equal to the metric of the reference's all-pairs scores within 1e-4."""
+    import golden_recipes as R
+    import evdr_amd.ops as ops
+    from evdr_amd import driver
+    from evdr_amd.evaluator.retrieval import score_multi_vector_masked, CustomRetrievalEvaluator
+    z = golden("config1_full")
+    want = torch.from_numpy(z["scores"])
+    Q, P, qm, pm, targets = R.config1_case()
+    docmap = {str(j): f"doc{j}" for j in range(500)}
+    qrels = {str(i): {docmap[str(int(t))]: 1} for i, t in enumerate(targets.tolist())}
+    ev = CustomRetrievalEvaluator()
+    m_ref = ev.compute_mteb_metrics(qrels, {str(i): {docmap[str(j)]: float(want[i, j]) for j in range(500)} for i in range(500)})
+    ws, wi = O.topk_rows(want, 100)
+    gap_ok = (ws[:, :-1] - ws[:, 1:]) > 2e-4
+    safe = torch.cat([gap_ok, gap_ok[:, -1:]], 1) & torch.cat([gap_ok[:, :1], gap_ok], 1)
+    for Qx, Px in ((Q.bfloat16(), P.bfloat16()), (Q, P)):                     # bf16 kernel; fp32 inputs -> fp16 hi/lo planes
+        got = score_multi_vector_masked(Qx.to(dev), Px.to(dev), qm.to(dev), pm.to(dev))
+        assert (got.cpu() - want).abs().max().item() < 1e-4
+        ts, ti = ops.topk(got, 100)
+        assert torch.equal(ti.cpu()[safe], wi[safe])
+        m = driver.eval_retrieval(ev, Qx.to(dev), qm.to(dev), Px.to(dev), pm.to(dev), qrels, docmap, None, k=100)
+        for fam, key in (("NDCG", "NDCG@5"), ("Recall", "Recall@1"), ("NDCG", "NDCG@10"), ("mRR", "MRR@10"), ("mAP", "MAP@100")):
+            assert abs(m[fam][key] - m_ref[fam][key]) <= 1e-4, (key, m[fam][key], m_ref[fam][key])

@@ -167,3 +167,14 @@ def test_c_oracle_matches_reference_fixtures_and_torch_oracle(golden):
     np.testing.assert_allclose(out, want.numpy(), atol=2e-5)
     assert np.array_equal(arg, warg.numpy())
     assert np.all(out[:, 4] == 0.0)
+
+
+def test_config1_full_size_slice_vs_reference(golden):
+    """BASELINE.json configs[1] at full size, scored by the reference itself (tests/golden/make_golden_config1.py): the oracle on a
+    slice of the same inputs (48 queries x 40 pages; the whole matrix is the GPU test's job) and the fixture's own sanity."""
+    z = golden("config1_full")
+    Q, P, qm, pm, targets = R.config1_case()
+    assert z["scores"].shape == (500, 500) and np.array_equal(z["targets"], targets.numpy()) and float(z["rank1"]) == 1.0
+    qs, ps = slice(100, 148), slice(230, 270)
+    got = O.maxsim_masked(Q[qs], P[ps], qm[qs], pm[ps], chunk_p=16)
+    np.testing.assert_allclose(got.numpy(), z["scores"][qs, ps], atol=1e-5, rtol=0)
