@@ -206,3 +206,17 @@ def config1_case():
     cut = lq - torch.randint(0, 13, (nq,), generator=gen)
     qm[torch.arange(lq)[None, :] >= cut[:, None]] = False
     return Q, P, qm, pm, targets
+
+
+def trajectory_case(steps: int = 8):
+    """A7 over several steps: the b4n8 capture's pages and masks with `steps` different seeded query batches (B = 4).
+    -> ([(Qb, qmb), ...], P_teacher_raw, pmask_t, Pbar0_raw, pmask_s, hyper-params)"""
+    _, _, Pt, pmt, Pbar0, pms, hp = train_case("b4n8")
+    gen = torch.Generator().manual_seed(31337)
+    batches = []
+    for s in range(steps):
+        Qb = _unit(gen, 4, 32, 128)
+        qmb = torch.ones(4, 32, dtype=torch.bool)
+        qmb[:, 28 - (s % 5):] = False
+        batches.append((Qb, qmb))
+    return batches, Pt, pmt, Pbar0, pms, hp

@@ -550,6 +550,44 @@ def test_stream_adamw_equals_torch_adamw(dev, shape):
     assert torch.isfinite(d).all() and not torch.equal(d.detach(), x0)
 
 
+@pytest.mark.parametrize("mode", ["call_pattern", "fused"])
+def test_a7_eight_step_trajectory(golden, dev, ER, mode):
+    """Eight consecutive steps against the trajectory the reference's OWN train_one_step produced
+    (tests/golden/make_golden_trajectory.py): every loss, the parameters after steps 1 / 4 / 8 and AdamW's moments --
+    through the drop-in modules used like the script (autograd + utils.set_optimizer) and through the fused step.  Pins the
+    optimizer's step count / bias corrections, the moments and the feedback of updated pages into the next forward."""
+    from evdr_amd import driver
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    from evdr_amd.utils.utils import set_optimizer
+    z = golden("a7_trajectory")
+    batches, Pt, pmt, Pbar0, pms, hp = R.trajectory_case()
+    Pt, pmt, Pbar0, pms = Pt.to(dev), pmt.to(dev), Pbar0.to(dev), pms.to(dev)
+    Ptn = l2_normalize(Pt * pmt.unsqueeze(-1)).detach()
+    big = torch.from_numpy(z["big"])
+    if mode == "call_pattern":
+        param = torch.nn.Parameter(Pbar0 * pms.unsqueeze(-1))
+        opt = set_optimizer("adamw", param, hp["lr"], hp["wd"])
+        step = lambda Qb, qmb: driver.train_one_step(Qb.to(dev), qmb.to(dev), Ptn, pmt, param, pms, opt, hp["temp"])
+        cur = lambda: (param.detach(), opt.state[param]["exp_avg"], opt.state[param]["exp_avg_sq"])
+    else:
+        teacher = driver.TeacherScorer(Ptn, pmt)
+        student = driver.FusedStudent(Pbar0, pms, lr=hp["lr"], weight_decay=hp["wd"])
+        step = lambda Qb, qmb: driver.fused_train_one_step(Qb.to(dev), qmb.to(dev), teacher, student, hp["temp"])
+        cur = lambda: (student.x, student.exp_avg, student.exp_avg_sq)
+    for i, (Qb, qmb) in enumerate(batches, 1):
+        loss = step(Qb, qmb)
+        np.testing.assert_allclose(loss, z["losses"][i - 1], rtol=2e-5, err_msg=f"step {i}")
+        if i in (1, 4, 8):
+            d = (cur()[0].cpu() - torch.from_numpy(z[f"param_after_{i}"])).abs()
+            # tight wherever the reference's own gradient was well above its summation noise (or exactly zero) in every step;
+            # elsewhere AdamW's m / (sqrt(v) + 1e-8) amplifies 1e-8-level noise, bounded by lr per step
+            assert d[big].max().item() < 3e-6 * i ** 0.5 + 1e-6, (i, d[big].max().item())
+            assert d.max().item() < 2 * i * hp["lr"]
+    _, ea, es = cur()
+    np.testing.assert_allclose(ea.cpu().numpy()[z["big"]], z["exp_avg"][z["big"]], atol=2e-6)
+    np.testing.assert_allclose(es.cpu().numpy()[z["big"]], z["exp_avg_sq"][z["big"]], atol=1e-9, rtol=2e-3)
+
+
 def test_stream_adamw_takes_torchs_step_whole_when_anything_is_ineligible(dev):
     """eligibility is decided before anything is touched.  A parameter that is a view at an odd storage offset
     (not 16-byte aligned), a gradient that is not dense, or moments restored onto another device make the WHOLE step torch's

@@ -178,3 +178,31 @@ def test_config1_full_size_slice_vs_reference(golden):
     qs, ps = slice(100, 148), slice(230, 270)
     got = O.maxsim_masked(Q[qs], P[ps], qm[qs], pm[ps], chunk_p=16)
     np.testing.assert_allclose(got.numpy(), z["scores"][qs, ps], atol=1e-5, rtol=0)
+
+
+def test_a7_eight_step_trajectory(golden):
+    """Eight consecutive steps of the reference's own train_one_step (tests/golden/make_golden_trajectory.py): the oracle's
+    restatement, driven the same way (one optimizer over all steps), reproduces every loss, the parameters after steps 1 / 4 / 8
+    and AdamW's moments."""
+    z = golden("a7_trajectory")
+    batches, Pt, pmt, Pbar0, pms, hp = R.trajectory_case()
+    Ptn = O.l2_normalize(Pt * pmt.unsqueeze(-1)).detach()
+    param = torch.nn.Parameter(Pbar0 * pms.unsqueeze(-1))
+    opt = torch.optim.AdamW([param], lr=hp["lr"], weight_decay=hp["wd"])
+    big = torch.from_numpy(z["big"])
+    for i, (Qb, qmb) in enumerate(batches, 1):
+        Ps = O.l2_normalize(param * pms.unsqueeze(-1))
+        with torch.no_grad():
+            sc_t = O.maxsim_masked(Qb, Ptn, qmb, pmt, 64)
+        loss = O.infonce_distill(O.maxsim_masked(Qb, Ps, qmb, pms, 64), sc_t, hp["temp"])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        np.testing.assert_allclose(loss.item(), z["losses"][i - 1], rtol=1e-5)
+        if i in (1, 4, 8):
+            d = (param.detach() - torch.from_numpy(z[f"param_after_{i}"])).abs()
+            assert d[big].max().item() < 1e-6 and d.max().item() < 2 * i * hp["lr"]
+    st = opt.state[param]
+    assert float(st["step"]) == float(z["step"]) == 8.0
+    np.testing.assert_allclose(st["exp_avg"].numpy(), z["exp_avg"], atol=1e-7)
+    np.testing.assert_allclose(st["exp_avg_sq"].numpy(), z["exp_avg_sq"], atol=1e-10, rtol=1e-4)
