@@ -40,18 +40,19 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True, experiment: bool = False, sentinel: bool = False,
-          ring_fault: bool = False) -> str:
+          ring_fault: int = 0) -> str:
     """Compile every HIP source for gfx950 and link libevdr.so; returns its path.  experiment=True builds
     libevdr_exp.so with -DEVDR_EXPERIMENT instead (the stamped diagnostic kernel instances used by scratch/; never
     loaded by the package).  sentinel=True builds libevdr_sentinel.so with -DEVDR_SENTINEL: the same kernels with every
     LDS-DMA piece poisoning its destination first (csrc/maxsim_device.h), loaded only by tests/test_gpu_sentinel.py.
-    ring_fault=True (scratch/sentinel_control.py only) removes the ring hand-over's vmcnt wait: libevdr[_sentinel]_fault.so."""
+    ring_fault (scratch/sentinel_control.py only): 1 removes the ring hand-over's vmcnt wait (a RAW race, libevdr[_sentinel]_fault.so),
+    2 issues the flat kernel's refill in front of the hand-over (a WAR race, libevdr[_sentinel]_faultwar.so)."""
     suffix = "_exp" if experiment else ("_sentinel" if sentinel else "")
-    suffix += "_fault" if ring_fault else ""
+    suffix += {0: "", 1: "_fault", 2: "_faultwar"}[int(ring_fault)]      # 1: hand-over without its vmcnt wait (RAW); 2: refill in front of it (WAR)
     obj_dir = OBJ_DIR + suffix
     lib_path = LIB_PATH.replace("libevdr.so", f"libevdr{suffix}.so")
     flags = FLAGS + (["-DEVDR_EXPERIMENT"] if experiment else []) + (["-DEVDR_SENTINEL"] if sentinel else []) + (
-        ["-DEVDR_RING_FAULT"] if ring_fault else [])
+        [f"-DEVDR_RING_FAULT={int(ring_fault)}"] if ring_fault else [])
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
@@ -87,4 +88,4 @@ def build(force: bool = False, verbose: bool = True, experiment: bool = False, s
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, experiment="--experiment" in sys.argv, sentinel="--sentinel" in sys.argv,
-          ring_fault="--ring-fault" in sys.argv)
+          ring_fault=2 if "--ring-fault-war" in sys.argv else int("--ring-fault" in sys.argv))

@@ -98,9 +98,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // wait that retires it"; scratch/audit_ring_isa.py checks every instance's listing for exactly this form).
 template <int N>
 __device__ __forceinline__ void ring_barrier() {
-#if defined(EVDR_RING_FAULT)
+#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT == 1
     // positive control of the sentinel instrument (scratch/sentinel_control.py; never a shipped build, and
     // scratch/audit_ring_isa.py rejects it): the hand-over WITHOUT its vmcnt wait, i.e. a deliberate read-before-landed race
+    // (EVDR_RING_FAULT == 2 is the WAR control: the flat kernel issues its refill IN FRONT of the hand-over, maxsim_fwd16.hip)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #elif defined(EVDR_RING_NOLGKM)
     // A/B only (scratch/r04_ab_hardening.sh): what the lgkmcnt(0) of the hand-over costs; rejected by scratch/audit_ring_isa.py

@@ -186,13 +186,20 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
     int slot = 0;
     for (int s = 0; s < nstages; ++s) {
         // stage s has landed once only the younger stages' pieces (NSTAGE-2 of them in steady state) remain
+#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT == 2
+        // WAR control of the sentinel instrument (never shipped): the refill of the slot stage s-1 was read from, issued BEFORE the
+        // hand-over, i.e. while slower waves may still be reading it
+        if (s + NSTAGE - 1 < nstages) issue_stage(s + NSTAGE - 1, slot == 0 ? NSTAGE - 1 : slot - 1);
+#endif
         // (waits + barrier as one statement: ring_barrier, maxsim_device.h)
         if (NSTAGE >= 3 && s + 1 < nstages) {
             if (NSTAGE >= 4 && s + 2 < nstages) ring_barrier<2 * G>(); else ring_barrier<G>();
         } else {
             ring_barrier<0>();
         }
+#if !(defined(EVDR_RING_FAULT) && EVDR_RING_FAULT == 2)
         if (s + NSTAGE - 1 < nstages) issue_stage(s + NSTAGE - 1, slot == 0 ? NSTAGE - 1 : slot - 1);
+#endif
         const char* sbase = smem + slot * STAGE_BYTES;
         if (active) {
 #pragma unroll

@@ -1,12 +1,15 @@
-"""Positive control of the sentinel instrument (tests/test_gpu_sentinel.py): the same scoring job through four builds of
-the same kernels --
-  libevdr.so                 product
-  libevdr_sentinel.so        product + poison in front of every LDS-DMA piece               -> must agree with the reference
-  libevdr_fault.so           ring hand-over WITHOUT its vmcnt wait (a deliberate RAW race)  -> wrong now and then, by little
-  libevdr_sentinel_fault.so  the same race under the sentinel                               -> wrong by ~1e36 wherever it bites
-Each build runs in a child process (one library handle per process).  What the control shows: how often a real
-read-before-landed race is visible WITHOUT the poison (the blind spot of bit-compare stress loops) and WITH it.
-usage: python scratch/sentinel_control.py            (parent: runs the four children)
+"""Positive control of the sentinel instrument (tests/test_gpu_sentinel.py): the same scoring jobs through builds of the same kernels --
+  libevdr.so                    product
+  libevdr_sentinel.so           product + poison in front of every LDS-DMA piece                 -> must agree with the reference
+  libevdr_fault.so              ring hand-over WITHOUT its vmcnt wait (a deliberate RAW race)    -> wrong now and then, by little
+  libevdr_sentinel_fault.so     the same race under the sentinel                                 -> wrong by ~1e36 wherever it bites
+  libevdr_faultwar.so           flat kernel: refill issued IN FRONT of the hand-over (WAR race)  -> overwrites tiles slower waves still read
+  libevdr_sentinel_faultwar.so  the same under the sentinel
+Job A: 256 queries x 2048 pages x 1030 patches (staged kernel; the RAW fault lives in every kernel's hand-over).
+Job B: 256 queries x 4096 pages x 200 patches (7 tiles: the flat 3-slot ring, where the WAR fault lives).
+Each build runs in a child process (one library handle per process).  What the control shows: how often a real ring race is
+visible WITHOUT the poison (the blind spot of bit-compare stress loops) and WITH it.
+usage: python scratch/sentinel_control.py            (parent: runs the children)
        python scratch/sentinel_control.py <libname>  (child)"""
 import os
 import subprocess
@@ -14,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIBS = ["libevdr.so", "libevdr_sentinel.so", "libevdr_fault.so", "libevdr_sentinel_fault.so"]
+LIBS = ["libevdr.so", "libevdr_sentinel.so", "libevdr_fault.so", "libevdr_sentinel_fault.so", "libevdr_faultwar.so", "libevdr_sentinel_faultwar.so"]
 
 
 def child(libname):
@@ -24,28 +27,29 @@ def child(libname):
     _lib.LIB_PATH = os.path.join(_lib.PKG_DIR, libname)
     from evdr_amd.corpus import PageCorpus
     dev = torch.device("cuda:0")
-    g = torch.Generator(device=dev).manual_seed(5)
-    n, nq = 2048, 256
-    P = torch.nn.functional.normalize(torch.randn((n, 1030, 128), generator=g, device=dev), dim=-1).bfloat16()
-    Q = torch.nn.functional.normalize(torch.randn((nq, 32, 128), generator=g, device=dev), dim=-1).bfloat16()
-    ref = torch.empty((nq, n), device=dev)
-    for lo in range(0, n, 64):                     # plain torch fp32 reference of the same op (bf16 products are exact in fp32)
-        sim = torch.einsum("qnd,pmd->qpnm", Q.float(), P[lo:lo + 64].float())
-        ref[:, lo:lo + 64] = sim.max(dim=3).values.sum(dim=2)
-    c = PageCorpus.from_tensor(P)
-    launches, wrong_launches, wrong_entries, huge_entries, worst = 0, 0, 0, 0, 0.0
-    for rep in range(40):
-        s = c.score(Q)
-        err = (s - ref).abs()
-        err = torch.where(torch.isfinite(err), err, torch.full_like(err, 1e38))
-        bad = err > 1e-4
-        launches += 1
-        wrong_launches += int(bad.any().item())
-        wrong_entries += int(bad.sum().item())
-        huge_entries += int((err > 1e3).sum().item())
-        worst = max(worst, err.max().item())
-    print(f"{libname:28s} launches {launches}  wrong launches {wrong_launches}  wrong entries {wrong_entries} of {launches * nq * n}"
-          f"  of them > 1e3: {huge_entries}  worst |err| {worst:.3e}", flush=True)
+    for job, (n, lp) in (("A 2048 x 1030", (2048, 1030)), ("B 4096 x 200 ", (4096, 200))):
+        g = torch.Generator(device=dev).manual_seed(5)
+        nq = 256
+        P = torch.nn.functional.normalize(torch.randn((n, lp, 128), generator=g, device=dev), dim=-1).bfloat16()
+        Q = torch.nn.functional.normalize(torch.randn((nq, 32, 128), generator=g, device=dev), dim=-1).bfloat16()
+        ref = torch.empty((nq, n), device=dev)
+        for lo in range(0, n, 64):                 # plain torch fp32 reference of the same op (bf16 products are exact in fp32)
+            sim = torch.einsum("qnd,pmd->qpnm", Q.float(), P[lo:lo + 64].float())
+            ref[:, lo:lo + 64] = sim.max(dim=3).values.sum(dim=2)
+        c = PageCorpus.from_tensor(P)
+        launches, wrong_launches, wrong_entries, huge_entries, worst = 0, 0, 0, 0, 0.0
+        for rep in range(40):
+            s = c.score(Q)
+            err = (s - ref).abs()
+            err = torch.where(torch.isfinite(err), err, torch.full_like(err, 1e38))
+            bad = err > 1e-4
+            launches += 1
+            wrong_launches += int(bad.any().item())
+            wrong_entries += int(bad.sum().item())
+            huge_entries += int((err > 1e3).sum().item())
+            worst = max(worst, err.max().item())
+        print(f"{libname:30s} job {job} {_lib.load().evdr_last_fwd_kernel().decode()[:44]:44s} wrong launches {wrong_launches:2d} of {launches}  wrong entries "
+              f"{wrong_entries:6d} of {launches * nq * n}  of them > 1e3: {huge_entries:6d}  worst |err| {worst:.3e}", flush=True)
 
 
 if __name__ == "__main__":
