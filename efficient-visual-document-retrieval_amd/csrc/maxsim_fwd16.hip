@@ -1248,6 +1248,17 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, i
             return qw == 2 ? launch16s<2, 2, false, 3, 2, false, true>(p, stream) : launch16s<1, 2, false, 3, 2, false, true>(p, stream);
         }
         if (want_argmax) return qw == 2 ? launch16s<2, 2, true, 4, 2, false, true>(p, stream) : launch16s<1, 2, true, 4, 2, false, true>(p, stream);
+        // Non-temporal corpus stream for a LARGE corpus read by at most two query groups (the frozen teacher of a training step:
+        // 32 queries x 500 x 1030 patches = 264 MB of planes, more than half of the 256-MiB Infinity Cache).  Such a stream gains
+        // nothing from the cache (each step evicts its own head before coming round) and, on the default policy, evicts what runs
+        // between two passes: the student's parameters, moments and planes, which the student forward and the update kernel
+        // re-read a few hundred microseconds later.  Measured inside the fused step (scratch/nt_teacher_ab.py, interleaved, same
+        // process): update kernel 86.5 -> 78.7 us, student forward 76.4 -> 74.2, teacher forward unchanged (the two workgroups
+        // that share a page chunk still meet in the XCD's L2), step 0.456 -> 0.442 ms; same bits.  geom 33 / 34 force it on / off.
+        const int64_t corpus_bytes = (int64_t)p.np * p.lp * EVDR_D * 2 * 2;
+        const int qgroups = (p.nq + 8 * qw - 1) / (8 * qw);
+        const bool nt2 = geom == 33 || (geom != 34 && qgroups <= 2 && corpus_bytes >= ((int64_t)128 << 20) && !p.per_token);
+        if (nt2) return qw == 2 ? launch16s<2, 2, false, 4, 2, false, true, 2, 8, true>(p, stream) : launch16s<1, 2, false, 4, 2, false, true, 2, 8, true>(p, stream);
         return qw == 2 ? launch16s<2, 2, false, 4, 2, false, true>(p, stream) : launch16s<1, 2, false, 4, 2, false, true>(p, stream);
     }
     if (want_argmax) return qw == 2 ? launch16s<2, 1, true, 8, 2, false, true>(p, stream) : launch16s<1, 1, true, 8, 2, false, true>(p, stream);

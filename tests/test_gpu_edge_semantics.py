@@ -372,3 +372,34 @@ def test_dp_is_bit_reproducible_and_matches_the_oracle(hot):
         outs.append((x, ea, es))
     for o in outs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+
+
+def test_large_teacher_corpus_streams_non_temporally_and_scores_the_same_bits():
+    """fp32 corpus of >= 128 MiB of planes read by at most two query groups (the frozen teacher of a training step,
+    mainv2_iter_distill_infonce.py:282-284): the forward takes its pages with the non-temporal policy so that the pass does not
+    evict the student state from the Infinity Cache (csrc/maxsim_fwd16.hip).  Cache policy only: same kernel body, same bits;
+    smaller corpora and launches with more query groups (which re-read page chunks from L2) keep the default policy."""
+    import evdr_amd  # noqa: F401
+    import evdr_amd.ops as ops
+    from evdr_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    unit = lambda *s: torch.nn.functional.normalize(torch.randn(*s, generator=g, device=DEV), dim=-1)
+    P = unit(260, 1030, 128)                                       # 260 x 1030 x 128 x 2 B x 2 planes = 137 MB
+    pm = torch.ones(260, 1030, dtype=torch.bool, device=DEV)
+    pm[5, 700:] = False
+    for nq, npg, want_nt in ((32, 260, True), (7, 260, True), (32, 200, False), (48, 260, False)):
+        Q = unit(nq, 32, 128)
+        qm = torch.ones(nq, 32, dtype=torch.bool, device=DEV)
+        got, _ = ops.maxsim_forward(Q, P[:npg], qm, pm[:npg])
+        name = lib.evdr_last_fwd_kernel().decode()
+        assert name.startswith("maxsim_fwd16s_kernel<") and name.endswith(",true>" if want_nt else ",false>"), (nq, npg, name)
+        lib.evdr_debug_set_fwd_variant(34 if want_nt else 33)      # the other policy, forced
+        try:
+            other, _ = ops.maxsim_forward(Q, P[:npg], qm, pm[:npg])
+            assert lib.evdr_last_fwd_kernel().decode() != name
+        finally:
+            lib.evdr_debug_set_fwd_variant(0)
+        assert torch.equal(got, other)
+        want = O.maxsim_masked(Q[:4].cpu(), P[:24].cpu(), qm[:4].cpu(), pm[:24].cpu())
+        np.testing.assert_allclose(got[:4, :24].cpu().numpy(), want.numpy(), atol=1e-4, rtol=0)
