@@ -5,7 +5,9 @@ temperature 0.1, AdamW(lr 1e-3, wd 1e-2).  Reports ms/step of the drop-in functi
 mainv2_iter_distill_infonce.py:269-292 ("call_pattern"), of the driver's resident-teacher step ("resident") and of
 the same with cached teacher scores ("cached"), of the fused student update ("fused", "fused_cached"; "_nosync": the loss
 stays on the device and the host queues the next step without waiting -- what driver.py --fused_step does between log
-lines) and of its HIP-graph replay ("fused_graph", "fused_cached_graph"); `--eager` adds a plain torch restatement of the
+lines; the epoch's batches are gathered and split into planes once per epoch, driver.EpochBatches, INSIDE the timed region:
+the first timed step opens an epoch; "fused_stepprep*": gather + split per step, the form before that) and of its HIP-graph
+replay ("fused_graph", "fused_cached_graph"); `--eager` adds a plain torch restatement of the
 reference's four ATen ops on the same GPU for context.
 
 `measure()` is also what bench.py calls for the `train_step` key of its JSON line (a short version: three modes, the
@@ -25,7 +27,8 @@ LT, LS, LQ, D = 1030, 206, 32, 128
 MFMA_F16_PEAK, MFMA_F32_PEAK, HBM_PEAK = 2500.0, 157.3, 8000.0    # TFLOP/s dense fp16/bf16, TFLOP/s fp32 MFMA, GB/s (MI355X_MICROARCH.md)
 PLANE_PRODUCTS = 3                                                 # lo*hi + hi*lo + hi*hi per fp32 product (csrc/maxsim_fwd16.hip)
 ALL_KINDS = ["call_pattern", "call_pattern_torch_adamw", "resident", "cached", "fused", "fused_cached", "fused_nosync", "fused_cached_nosync", "fused_graph",
-             "fused_cached_graph", "fused_overlap", "fused_overlap_nosync"]
+             "fused_cached_graph", "fused_overlap", "fused_overlap_nosync", "fused_stepprep", "fused_stepprep_nosync"]
+EPOCH = 64                                                         # batches per epoch of the benchmark's query set (64 * B queries)
 
 
 def eager_maxsim(Q, P, qmask, pmask, chunk_p=64):
@@ -67,6 +70,10 @@ def time_mode(inp, kind: str, steps: int, warmup: int):
     # one-pass update kernel; "call_pattern_torch_adamw" keeps torch's own foreach AdamW for the A/B
     opt = torch.optim.AdamW([param], lr=1e-3, weight_decay=1e-2) if kind == "call_pattern_torch_adamw" else set_optimizer("adamw", param, 1e-3, 1e-2)
     cached = kind in ("cached", "fused_cached", "fused_cached_graph", "fused_cached_nosync")
+    stepprep = "_stepprep" in kind
+    kind = kind.replace("_stepprep", "")
+    use_epoch = kind in ("fused", "fused_cached", "fused_nosync", "fused_cached_nosync") and not stepprep
+    epoch = [None]
     teacher = driver.TeacherScorer(Pt, pmt, cache_size=Qall.shape[0] if cached else 0) if kind not in ("call_pattern", "call_pattern_torch_adamw", "eager") else None
     student = driver.FusedStudent(Pbar0.clone(), pms, lr=1e-3, weight_decay=1e-2) if kind.startswith("fused") else None
     graphed = student.graphed(B, LQ, 0.1, None if cached else teacher) if kind.endswith("_graph") else None
@@ -74,9 +81,15 @@ def time_mode(inp, kind: str, steps: int, warmup: int):
     def step(i):
         # as in driver.py: the epoch's index order lives on the device (uploaded once per epoch), a batch's indices are a
         # view of it; the host copy of the indices only keys the teacher-score cache
-        lo = (i % 64) * B
+        lo = (i % EPOCH) * B
         idx, idx_dev = order[lo:lo + B], order_dev[lo:lo + B]
-        Qb, qmb = Qall.index_select(0, idx_dev), qmall.index_select(0, idx_dev)
+        qpl = None
+        if use_epoch:
+            if i % EPOCH == 0 or epoch[0] is None:                  # a new epoch: one gather + one split launch for all its batches
+                epoch[0] = driver.EpochBatches(Qall, qmall, order_dev, B)
+            Qb, qmb, qpl = epoch[0].get(i % EPOCH)
+        else:
+            Qb, qmb = Qall.index_select(0, idx_dev), qmall.index_select(0, idx_dev)
         if kind in ("resident", "cached"):
             return driver.train_one_step(Qb, qmb, teacher, pmt, param, pms, opt, temp=0.1, qidx=idx if kind == "cached" else None)
         if kind == "fused_graph":                       # teacher forward + student update: one HIP-graph replay
@@ -84,12 +97,12 @@ def time_mode(inp, kind: str, steps: int, warmup: int):
         if kind == "fused_cached_graph":                # teacher scores from the cache, student update replayed
             return float(graphed(Qb, qmb, teacher.scores(Qb, qmb, idx)).item())
         if kind in ("fused", "fused_cached"):
-            return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached" else None)
+            return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached" else None, qplanes=qpl)
         if kind in ("fused_overlap", "fused_overlap_nosync"):   # student forward on a second stream beside the teacher forward
             return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, sync=kind == "fused_overlap", overlap=True)
         if kind in ("fused_nosync", "fused_cached_nosync"):     # loss stays on the device: no host sync inside the timed loop
             return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached_nosync" else None,
-                                               sync=False)
+                                               sync=False, qplanes=qpl)
         score = eager_maxsim if kind == "eager" else score_multi_vector_masked
         Psb = l2_normalize(param * pms.unsqueeze(-1))
         with torch.no_grad():
@@ -105,10 +118,11 @@ def time_mode(inp, kind: str, steps: int, warmup: int):
         return float(loss.item())
 
     if cached:
-        for i in range(64):
+        for i in range(EPOCH):
             step(i)                                   # fill the teacher-score cache (one epoch)
     for i in range(warmup):
         step(i)
+    epoch[0] = None                                   # the first timed step opens its epoch inside the timed region
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -210,6 +224,7 @@ def in_step_kernel_ms(inp, steps: int = 40, warmup: int = 10):
     teacher = driver.TeacherScorer(Pt, pmt)
     student = driver.FusedStudent(Pbar0.clone(), pms, lr=1e-3, weight_decay=1e-2)
     rec = {"teacher": [], "student": [], "update": []}
+    order_dev = torch.arange(Qall.shape[0], device=inp["dev"])
     live = [False]
     orig_f, orig_u = ops.maxsim_forward_prepared, ops.maxsim_backward_adamw
 
@@ -232,8 +247,10 @@ def in_step_kernel_ms(inp, steps: int = 40, warmup: int = 10):
                 torch.cuda.synchronize()
                 live[0] = True
                 t0 = time.perf_counter()
-            lo = (i % 64) * B
-            driver.fused_train_one_step(Qall[lo:lo + B], qmall[lo:lo + B], teacher, student, 0.1, sync=False)
+            if i % EPOCH == 0 or i == warmup:
+                eb = driver.EpochBatches(Qall, qmall, order_dev, B)
+            Qb, qmb, qpl = eb.get(i % EPOCH)
+            driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, sync=False, qplanes=qpl)
         torch.cuda.synchronize()
         t_step = 1e3 * (time.perf_counter() - t0) / steps
     finally:

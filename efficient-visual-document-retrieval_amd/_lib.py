@@ -21,6 +21,7 @@ SIGNATURES = {
     "evdr_last_error": (C.c_char_p, []),
     "evdr_pack_pmask": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "evdr_split_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "evdr_split_f32_segments": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "evdr_maxsim_fwd_workspace": (_sz, [_i64, _i64, _i64, _i64, C.c_int]),
     "evdr_maxsim_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
     "evdr_maxsim_fwd_prepared": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64,

@@ -137,6 +137,15 @@ int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* ama
     return e == hipSuccess ? EVDR_OK : hip_fail(e, "split_f32 launch");
 }
 
+int evdr_split_f32_segments(const float* x, int64_t rows, int64_t seg_rows, uint16_t* planes, uint32_t* amax_bits, void* hip_stream) {
+    if (rows < 0) return fail(EVDR_ERR_ARG, "evdr_split_f32_segments: negative rows");
+    if (seg_rows < 1 || seg_rows > 2048) return fail(EVDR_ERR_ARG, "evdr_split_f32_segments: seg_rows outside 1..2048");
+    if ((rows + seg_rows - 1) / seg_rows > 65535) return fail(EVDR_ERR_ARG, "evdr_split_f32_segments: more than 65535 segments");
+    if (rows > 0 && (!x || !planes || !amax_bits)) return fail(EVDR_ERR_ARG, "evdr_split_f32_segments: null pointer");
+    hipError_t e = evdr_launch_split_f32_segments(x, rows, seg_rows, planes, amax_bits, (hipStream_t)hip_stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "split_f32_segments launch");
+}
+
 int evdr_flag_nonfinite(const void* P, int dtype, const uint8_t* pmask, int64_t np, int64_t lp, int64_t p_stride,
                         uint32_t* pageflags, void* hip_stream) {
     if (int rc = check_common(0, 0, np, lp)) return rc;

@@ -108,6 +108,8 @@ hipError_t evdr_launch_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp, 
 hipError_t evdr_launch_build_qlist(const uint8_t* qmask, int64_t nq, int64_t lq, int64_t tok0, int32_t* qlist, int32_t* qcount,
                                    hipStream_t stream);
 hipError_t evdr_launch_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, hipStream_t stream);
+hipError_t evdr_launch_split_f32_segments(const float* x, int64_t rows, int64_t seg_rows, uint16_t* planes, uint32_t* amax_bits,
+                                          hipStream_t stream);
 hipError_t evdr_launch_split_f32_pages(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, const uint8_t* rowmask,
                                        int64_t rows_per_page, uint32_t* pageflags, hipStream_t stream);
 hipError_t evdr_launch_flag_nonfinite(const void* P, int kind, const uint8_t* pmask, int64_t np, int64_t lp, int64_t p_stride,

@@ -201,6 +201,65 @@ __global__ void __launch_bounds__(1024) split_small_kernel(const float* __restri
     }
 }
 
+// The same for MANY small tensors laid end to end (the batches of a training epoch: segment s = rows [s R, s R + R) of x,
+// the last one possibly short): blockIdx.y = segment, each workgroup reduces ITS segment's absmax and splits its own 8192
+// floats of it.  Every segment keeps its own absmax word and power of two, so its planes are bit for bit what
+// split_small_kernel gives for that batch alone; segment s's planes are one contiguous (2, rows_s, 128) block at
+// planes + s * 2 * R * 128 (the layout evdr_maxsim_fwd_prepared takes for the queries).
+__global__ void __launch_bounds__(1024) split_segments_kernel(const float* __restrict__ x, int64_t rows, int64_t seg_rows,
+                                                              uint32_t* __restrict__ amax_bits, _Float16* __restrict__ planes) {
+    const int64_t seg = blockIdx.y;
+    const int64_t r0 = seg * seg_rows;
+    const int64_t nrows = min(seg_rows, rows - r0);
+    const float* xs = x + r0 * EVDR_D;
+    const int64_t n8 = nrows * (EVDR_D / 8), n4 = n8 * 2;
+    uint32_t m = 0;
+    auto fold = [&](const f32x4& v) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float f = v[k];
+            const uint32_t b = __builtin_bit_cast(uint32_t, f) & 0x7FFFFFFFu;
+            if (b < 0x7F800000u) m = max(m, b);                  // non-finite elements do not set the scale (absmax_kernel)
+        }
+    };
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 1024 < n4; i += 8 * 1024) {                   // eight 16-B loads in flight per thread
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(xs + (i + u * 1024) * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fold(v[u]);
+    }
+    for (; i < n4; i += 1024) fold(*reinterpret_cast<const f32x4*>(xs + i * 4));
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    __shared__ uint32_t wmax[16];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) m = max(m, wmax[w]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) amax_bits[seg] = m;
+    const int k = evdr_h2_shift(m);
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+    _Float16* hi = planes + seg * 2 * seg_rows * EVDR_D;
+    _Float16* lo = hi + nrows * EVDR_D;
+    const int64_t e = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (e < n8) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(xs + e * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(xs + e * 8 + 4);
+        f16x8 a, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = __builtin_ldexpf((j < 4) ? v0[j & 3] : v1[j & 3], k);
+            const _Float16 h = (_Float16)f;
+            a[j] = h;
+            b[j] = (_Float16)(f - (float)h);
+        }
+        *reinterpret_cast<f16x8*>(hi + e * 8) = a;
+        *reinterpret_cast<f16x8*>(lo + e * 8) = b;
+    }
+}
+
 // Stable compaction of the queries that have a valid token in [tok0, tok0 + 32): one workgroup, 256 queries per round.
 __global__ void __launch_bounds__(256) build_qlist_kernel(const uint8_t* __restrict__ qmask, int nq, int lq, int tok0,
                                                          int32_t* __restrict__ qlist, int32_t* __restrict__ qcount) {
@@ -252,6 +311,17 @@ hipError_t evdr_launch_flag_nonfinite(const void* P, int kind, const uint8_t* pm
     if (blocks > 256 * 8) blocks = 256 * 8;
     auto kern = kind == 0 ? nonfinite_scan_kernel<0> : (kind == 1 ? nonfinite_scan_kernel<1> : nonfinite_scan_kernel<2>);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, P, pmask, np, lp, p_stride, pageflags);
+    return hipGetLastError();
+}
+
+// segments of `seg_rows` rows each (<= 2048: one workgroup reads a whole segment for its absmax), the last one short
+hipError_t evdr_launch_split_f32_segments(const float* x, int64_t rows, int64_t seg_rows, uint16_t* planes, uint32_t* amax_bits,
+                                          hipStream_t stream) {
+    if (rows == 0) return hipSuccess;
+    const int64_t nseg = (rows + seg_rows - 1) / seg_rows;
+    const int64_t n8 = seg_rows * (EVDR_D / 8);
+    hipLaunchKernelGGL(split_segments_kernel, dim3((unsigned)((n8 + 1023) / 1024), (unsigned)nseg), dim3(1024), 0, stream, x, rows, seg_rows,
+                       amax_bits, (_Float16*)planes);
     return hipGetLastError();
 }
 

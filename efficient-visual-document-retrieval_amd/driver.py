@@ -400,6 +400,9 @@ def run(args) -> None:
             # resident pseudo-queries: the epoch's permutation goes to the device once, a batch's indices are a view of it
             # (no index upload per step) and the rows come out with index_select (half the host cost of advanced indexing)
             perm_dev = perm.to(Q_train.device) if Q_train.is_cuda else None
+            # single-process fused steps: the epoch's batches are gathered and split into planes once per epoch (EpochBatches)
+            use_epoch = student is not None and world == 1 and perm_dev is not None and args.q_batch * Q_train.shape[1] <= 2048
+            epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch) if use_epoch else None
             t0, loss_sum, loss_cnt = time.time(), 0.0, 0
             # fused single-process steps leave their loss on the device; the host reads the pending ones when a line is due
             # (same numbers, same double-precision running sum in the same order: one sync per log line, not per step)
@@ -422,12 +425,18 @@ def run(args) -> None:
                 if cursor >= n_train:                               # epoch boundary: reshuffle (DataLoader(shuffle=True))
                     perm, cursor = torch.randperm(n_train, generator=gen), 0
                     perm_dev = perm.to(Q_train.device) if Q_train.is_cuda else None
+                    if use_epoch:
+                        epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch)
                 idx = perm[cursor:cursor + args.q_batch]
                 qidx = idx if args.cache_teacher_scores else None
                 if perm_dev is not None:
                     idx = perm_dev[cursor:cursor + args.q_batch]
+                qpl_step = None
+                if use_epoch:
+                    Qb_step, qmb_step, qpl_step = epoch.get(cursor // args.q_batch)
+                else:
+                    Qb_step, qmb_step = Q_train.index_select(0, idx), qmask_train.index_select(0, idx)
                 cursor += args.q_batch
-                Qb_step, qmb_step = Q_train.index_select(0, idx), qmask_train.index_select(0, idx)
                 if world > 1 and student is not None:
                     loss_val = sharded_fused_train_one_step(Qb_step, qmb_step, teacher, student, args.temp,
                                                            shard_sizes, qidx=qidx)
@@ -436,7 +445,7 @@ def run(args) -> None:
                                                      args.temp, shard_sizes, qidx=qidx)
                 elif student is not None:
                     loss_val = fused_train_one_step(Qb_step, qmb_step, teacher, student, args.temp, qidx=qidx,
-                                                    sync=not defer)
+                                                    sync=not defer, qplanes=qpl_step)
                 else:
                     loss_val = train_one_step(Qb_step, qmb_step, teacher, pmask_t, Pbar_param, pmask_s, opt,
                                               temp=args.temp, qidx=qidx)
@@ -479,6 +488,33 @@ def run(args) -> None:
             if tb is not None:
                 tb.flush()
                 tb.close()
+
+
+class EpochBatches:
+    """The pseudo-queries of ONE epoch in batch order, prepared when the epoch starts instead of step by step.  The reference
+    draws its batches from DataLoader(shuffle=True) (mainv2_iter_distill_infonce.py:81,168-178): the epoch's permutation fixes
+    every batch up front, so the rows are gathered with ONE index_select per epoch (not two per step) and -- for the fused
+    step -- split into the scorer's fp16 hi/lo planes in ONE launch (ops.split_f32_segments: every batch keeps its own absmax
+    word, i.e. its planes are bit for bit what ops.split_f32 of that batch gives).  A step then launches nothing in front of
+    its teacher forward: 3 launches (~18 us of mostly launch latency on the step's critical path) become views.
+    Costs one gathered fp32 copy of the query set plus its planes (2 x 16 KiB per 32-token query)."""
+
+    def __init__(self, Q: torch.Tensor, qmask: torch.Tensor, perm: torch.Tensor, batch: int, planes: bool = True):
+        self.batch = int(batch)
+        self.Q = Q.index_select(0, perm)
+        self.qmask = qmask.index_select(0, perm)
+        self.n = int(self.Q.shape[0])
+        self.planes = ops.split_f32_segments(self.Q, self.batch) if (planes and self.Q.is_cuda and self.n) else None
+
+    def __len__(self) -> int:
+        return (self.n + self.batch - 1) // self.batch
+
+    def get(self, i: int):
+        """(Qb, qmb, qplanes or None) of batch i: views."""
+        lo = i * self.batch
+        Qb, qmb = self.Q[lo:lo + self.batch], self.qmask[lo:lo + self.batch]
+        qpl = ops.segment_planes(*self.planes, i, Qb.shape) if self.planes is not None else None
+        return Qb, qmb, qpl
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -645,7 +681,7 @@ class GraphedStep:
 
 
 def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStudent, temp: float,
-                         qidx: Optional[torch.Tensor] = None, sync: bool = True, overlap: bool = False):
+                         qidx: Optional[torch.Tensor] = None, sync: bool = True, overlap: bool = False, qplanes=None):
     """One fused update.  sync=True returns float(loss) like the reference's train_one_step (one host wait per step, for the
     loss only: the parameter update may still be running when it returns -- later work on the stream is ordered behind it);
     sync=False returns the loss as a device scalar and leaves the stream running, so that the host queues the next step
@@ -653,11 +689,13 @@ def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStuden
     overlap=True issues the student forward on a second stream beside the teacher forward (the two are independent; the
     loss waits for both).  Measured on MI355X (profiles/r03_experiments.txt): 0.4625 ms per step against 0.438 -- SLOWER.
     Both kernels fill the chip with one 256-register workgroup per CU that takes most of the LDS, so workgroups of the two
-    launches cannot share a CU and only trade places, and the events cost host time; kept as an option for the A/B only."""
+    launches cannot share a CU and only trade places, and the events cost host time; kept as an option for the A/B only.
+    `qplanes`: the batch's (planes, absmax word) when they exist already (EpochBatches: split once per epoch)."""
     device = student.x.device
     Qb = Qb.to(device, non_blocking=True).float()
     qmb = qmb.to(device, non_blocking=True)
-    qplanes = ops.split_f32(Qb)                                      # once per step, shared by teacher and student
+    if qplanes is None:
+        qplanes = ops.split_f32(Qb)                                  # once per step, shared by teacher and student
     scored = None
     if overlap:
         main = torch.cuda.current_stream(device)

@@ -103,6 +103,38 @@ def split_f32(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return planes, amax
 
 
+def split_f32_segments(x: torch.Tensor, seg: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`split_f32` of consecutive groups of `seg` leading entries of x (n, ..., 128) in ONE launch -- the batches of a training
+    epoch, known when the epoch starts.  Returns (planes, absmax words): planes (nseg, 2 * seg * rows_per_entry * 128) fp16,
+    one row per segment, absmax (nseg,) int32; `segment_planes` cuts out segment s in `split_f32`'s format.  Every segment
+    keeps its own absmax word: bit for bit the planes `split_f32(x[s * seg:(s + 1) * seg])` makes."""
+    dev = _require_cuda(x)
+    if x.shape[-1] != D:
+        raise NotImplementedError(f"embedding width {x.shape[-1]} unsupported (kernels are built for {D})")
+    xc = x.float().contiguous()
+    n = xc.shape[0]
+    per = (xc.numel() // D) // max(n, 1)                       # rows per leading entry
+    if seg < 1 or seg * per > 2048:
+        raise ValueError(f"segments of {seg} x {per} rows: one segment is at most 2048 rows")
+    nseg = (n + seg - 1) // seg
+    planes = torch.empty((nseg, 2 * seg * per * D), dtype=torch.float16, device=dev)
+    amax = torch.empty((max(nseg, 1),), dtype=torch.int32, device=dev)
+    if n:
+        lib = L.load()
+        with L.on(dev):
+            L.check(lib.evdr_split_f32_segments(L.ptr(xc), n * per, seg * per, L.ptr(planes), L.ptr(amax), L.current_stream_handle(dev)))
+    return planes, amax
+
+
+def segment_planes(planes: torch.Tensor, amax: torch.Tensor, s: int, shape) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Segment s of `split_f32_segments` as ((2,) + shape fp16 planes, its absmax word): views, nothing is copied.  `shape` =
+    shape of the fp32 batch (a short last batch has fewer leading entries)."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return planes[s, : 2 * n].view((2,) + tuple(int(d) for d in shape)), amax[s:s + 1]
+
+
 def maxsim_forward(Q: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],
                    want_argmax: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """A1 (evaluator/retrieval.py:166-213) through evdr_maxsim_fwd.  bf16 x bf16 inputs are scored as

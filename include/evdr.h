@@ -89,6 +89,15 @@ int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp,
  * planes).  Three fp16 MFMA products lo*hi + hi*lo + hi*hi then give the fp32 dot product to below fp32 rounding noise. */
 int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, void* hip_stream);
 
+/* evdr_split_f32 of MANY small tensors laid end to end, in one launch: segment s = rows [s * seg_rows, (s + 1) * seg_rows) of
+ * x (the last segment may be short; seg_rows <= 2048, at most 65535 segments) -- the batches of a training epoch, whose
+ * queries are known when the epoch starts (the reference draws them per step from a DataLoader,
+ * mainv2_iter_distill_infonce.py:81).  Every segment keeps ITS OWN absmax word amax_bits[s] and power of two: its planes
+ * are bit for bit those of evdr_split_f32 applied to that segment alone.  Segment s's planes are the contiguous
+ * (2, rows_s, 128) block at planes + s * 2 * seg_rows * 128 -- what evdr_maxsim_fwd_prepared takes as Q planes.
+ * planes: 2 * rows * 128 uint16 (rounded up to whole segments: ceil(rows / seg_rows) * 2 * seg_rows * 128). */
+int evdr_split_f32_segments(const float* x, int64_t rows, int64_t seg_rows, uint16_t* planes, uint32_t* amax_bits, void* hip_stream);
+
 /* Report non-finite page content: sets bit 3 of pageflags[p] (made by evdr_pack_pmask) when a valid patch of page p holds a
  * NaN or +-Inf element; the forward kernels then return NaN for that page ("Non-finite inputs" above).  P: (np, lp, 128)
  * of dtype EVDR_F32, EVDR_BF16 or EVDR_F16 (the hi plane of fp16 hi/lo planes), `p_stride` elements between pages.  One

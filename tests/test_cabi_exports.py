@@ -55,6 +55,10 @@ def test_argument_errors_need_no_gpu(lib):
     assert rc == L.EVDR_ERR_ARG and b"k=500" in lib.evdr_last_error()
     rc = lib.evdr_infonce_distill_fwd_bwd(None, None, 4, 4, ctypes.c_float(0.0), None, None, None, None)
     assert rc == L.EVDR_ERR_ARG
+    rc = lib.evdr_split_f32_segments(None, 64, 4096, None, None, None)
+    assert rc == L.EVDR_ERR_ARG and b"seg_rows" in lib.evdr_last_error()
+    assert lib.evdr_split_f32_segments(None, 0, 1024, None, None, None) == L.EVDR_OK      # nothing to split
+    assert lib.evdr_split_f32_segments(None, 64, 32, None, None, None) == L.EVDR_ERR_ARG   # null pointers
     assert lib.evdr_maxsim_fwd_workspace(8, 32, 64, 1030, L.EVDR_F32) > 2 * 64 * 1030 * 128 * 2
     assert lib.evdr_maxsim_fwd_workspace(8, 32, 64, 1030, L.EVDR_BF16) < 64 * 1030 * 4
     assert lib.evdr_maxsim_topk_workspace(10, 10) >= 400

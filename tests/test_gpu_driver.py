@@ -302,6 +302,51 @@ def test_fused_step_with_the_student_forward_on_a_second_stream(golden):
         assert torch.equal(b.x, a.x) and torch.equal(b.exp_avg, a.exp_avg) and torch.equal(b.exp_avg_sq, a.exp_avg_sq)
 
 
+def test_epoch_batches_give_the_per_step_batches_and_planes_bit_for_bit(golden):
+    """driver.EpochBatches (one gather and ONE split launch per epoch, evdr_split_f32_segments) hands out exactly what the
+    per-step form makes -- index_select of the batch's rows + ops.split_f32 of the batch, each batch with its own absmax
+    word -- also for the short last batch; the fused step fed from it leaves the same bits as the per-step form."""
+    import evdr_amd  # noqa: F401
+    import golden_recipes as R
+    from evdr_amd import driver, ops
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(11)
+    B, n = 32, 5 * 32 + 7                                          # five full batches and a short one
+    Q = torch.nn.functional.normalize(torch.randn(n, 32, 128, generator=gen), dim=-1)
+    Q[40:72] *= 3.0                                                # one batch in another binade: its own power of two
+    Q[100, 3, 5] = float("inf")                                    # non-finite elements do not set a batch's scale
+    Q, qm = Q.to(dev), (torch.rand(n, 32, generator=gen) > 0.2).to(dev)
+    perm = torch.randperm(n, generator=gen).to(dev)
+    eb = driver.EpochBatches(Q, qm, perm, B)
+    assert len(eb) == 6
+    for i in range(len(eb)):
+        idx = perm[i * B:(i + 1) * B]
+        Qb, qmb, (pl, am) = eb.get(i)
+        wantQ, wantm = Q.index_select(0, idx), qm.index_select(0, idx)
+        wpl, wam = ops.split_f32(wantQ)
+        assert torch.equal(Qb.view(torch.int32), wantQ.view(torch.int32)) and torch.equal(qmb, wantm)
+        assert pl.shape == wpl.shape and pl.is_contiguous() and torch.equal(pl.view(torch.int16), wpl.view(torch.int16))
+        assert torch.equal(am, wam)
+    with pytest.raises(ValueError):
+        ops.split_f32_segments(Q, 65)                              # 65 x 32 rows: more than one workgroup's segment
+
+    Qb, qmb, Pt, pmt, Pbar0, pms, hp = R.train_case("b32n128")
+    teacher = driver.TeacherScorer(l2_normalize(Pt * pmt.unsqueeze(-1)).to(dev), pmt.to(dev))
+    a = driver.FusedStudent(Pbar0.to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+    b = driver.FusedStudent(Pbar0.to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"])
+    Qn = torch.nn.functional.normalize(torch.randn(n, 32, 128, generator=gen), dim=-1).to(dev)
+    eb = driver.EpochBatches(Qn, qm, perm, B)
+    for i in range(len(eb)):
+        idx = perm[i * B:(i + 1) * B]
+        la = driver.fused_train_one_step(Qn.index_select(0, idx), qm.index_select(0, idx), teacher, a, hp["temp"])
+        Qi, qi, qpl = eb.get(i)
+        lb = driver.fused_train_one_step(Qi, qi, teacher, b, hp["temp"], qplanes=qpl)
+        assert la == lb
+    torch.cuda.synchronize()
+    assert torch.equal(b.x, a.x) and torch.equal(b.exp_avg, a.exp_avg) and torch.equal(b.exp_avg_sq, a.exp_avg_sq)
+
+
 def test_two_graphed_steps_of_one_batch_size_captured_before_either_replays(golden):
     """the loss workspace (row losses + ticket word) of the one-launch InfoNCE kernel is owned by the student and
     zeroed OUTSIDE the capture.  Two GraphedSteps of the same batch size -- two students, both captured before either has
