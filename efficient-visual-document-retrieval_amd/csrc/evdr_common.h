@@ -1,5 +1,6 @@
 // Shared declarations for the gfx950 kernels and the C-ABI dispatch (include/evdr.h).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -81,14 +82,16 @@ static inline int evdr_pages_per_block(int64_t np, int64_t n_qgroups, int64_t nt
 
 // The dynamic-LDS limit of a kernel is a per-(function, device) attribute: remember the devices it was raised on, so that
 // one process driving several GPUs (torch.cuda.set_device between calls) gets it on each of them.
-static inline hipError_t evdr_ensure_dyn_lds(const void* kern, int bytes, uint64_t& devs_done) {
+// Safe from several host threads: the bit set is atomic, and two threads that both find the bit clear both raise the limit
+// to the same value (idempotent) before either launches.
+static inline hipError_t evdr_ensure_dyn_lds(const void* kern, int bytes, std::atomic<uint64_t>& devs_done) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const uint64_t bit = 1ull << (dev & 63);
-    if (devs_done & bit) return hipSuccess;
+    if (devs_done.load(std::memory_order_acquire) & bit) return hipSuccess;
     e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) devs_done |= bit;
+    if (e == hipSuccess) devs_done.fetch_or(bit, std::memory_order_release);
     return e;
 }
 

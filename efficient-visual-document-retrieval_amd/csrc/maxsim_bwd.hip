@@ -669,7 +669,7 @@ static hipError_t launch_bwd(const float* g, const float* Q, const uint8_t* qmas
     constexpr int CW = (CHUNK / BW_THREADS * (BW_THREADS / 64) + 3) / 4;
     constexpr int LDS = BW_ROWS * EVDR_D * 4 + CHUNK * 8 + BW_ROWS * 8 + BW_ROWS * CW * 4;
     auto kern = maxsim_bwd_kernel<BW_ROWS, CHUNK, FUSED>;
-    static uint64_t attr_devs = 0;
+    static std::atomic<uint64_t> attr_devs{0};
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     dim3 grid((unsigned)np, (unsigned)((lp + BW_ROWS - 1) / BW_ROWS));
     hipLaunchKernelGGL(kern, grid, dim3(BW_THREADS), LDS, stream, g, Q, qmask, pmask, argmax, dP, (int)nq, (int)lq, (int)np,

@@ -1165,7 +1165,7 @@ hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
     constexpr int LDS = NSTAGE * (ST + 1) * NPL * TILE_BYTES;
     auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC, WAVES, NT>;
-    static uint64_t attr_devs = 0;
+    static std::atomic<uint64_t> attr_devs{0};
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, WAVES * QW, LDS <= 80 * 1024 ? 2 : 1);      // two workgroups share a CU's 160 KiB, or one owns it
     static const char* const name = [] {
@@ -1184,7 +1184,7 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
     constexpr int LDS = NSTAGE * ST * TILE_BYTES;
     auto kern = maxsim_fwd16_kernel<QW, WAVES, ST, NSTAGE>;
-    static uint64_t attr_devs = 0;
+    static std::atomic<uint64_t> attr_devs{0};
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, WAVES * QW);
     static const char* const name = [] {

@@ -14,13 +14,15 @@
  *   - nothing here allocates, frees or synchronises: scratch memory comes in through
  *     `workspace` (query the size first), work is enqueued on `hip_stream` (a hipStream_t, may
  *     be NULL for the default stream) and the call returns immediately (graph-capture safe);
- *   - THREADING: the library is meant to be driven by ONE host thread per process, as the reference drives its scorer (a single
- *     Python thread, DataLoader(num_workers=0); mainv2_iter_distill_infonce.py:269-321).  Concurrent calls from several host
- *     threads are not supported: the first launch of each kernel instance raises that kernel's dynamic-LDS limit and
- *     remembers the device in an unsynchronised function-local static (csrc/maxsim_fwd16.hip: launch16s / launch16), and the
- *     debug hooks below are process-wide.  Different STREAMS from that one thread are fine (nothing here synchronises), and
- *     so are several processes per node (one per GPU: corpus.py / bench.py).  evdr_last_error() and evdr_last_fwd_kernel()
- *     are thread-local only so that a host-side error text is never torn; that is not a threading guarantee for the launches;
+ *   - THREADING: entry points may be called from several host threads at once, each call on whatever stream it names (the
+ *     reference itself drives its scorer from a single Python thread, DataLoader(num_workers=0);
+ *     mainv2_iter_distill_infonce.py:269-321).  The library keeps no mutable state between calls except (a) per kernel
+ *     instance, the set of devices on which its dynamic-LDS limit has been raised -- an atomic bit set, and raising the limit
+ *     twice is harmless -- and (b) the process-wide debug hooks below (atomics: a test tool, not for concurrent use).
+ *     evdr_last_error() and evdr_last_fwd_kernel() are thread-local: a thread reads its own.  Ordering between calls that
+ *     touch the same buffers is the caller's (streams / events), as with any HIP launch; workspaces are per call.
+ *     tests/cabi/cabi_threads.cpp: eight threads, one kernel family each, first launches racing, bit-equal to serial calls.
+ *     Several processes per node (one per GPU: corpus.py / bench.py) are the multi-GPU form;
  *   - D (embedding width) must be 128 (ColPali / ColQwen projection width);
  *   - masks are one byte per token, 0 = masked (torch.bool storage);
  *   - dtype: EVDR_F32 inputs are scored to fp32 accuracy (fp16 hi/lo planes of the power-of-two-scaled

@@ -22,6 +22,21 @@ def test_cabi_from_plain_cpp(tmp_path):
     assert r.returncode == 0 and "cabi_smoke OK" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
+def test_cabi_from_several_host_threads(tmp_path):
+    """Eight host threads, each with its own stream, buffers and problem shape (one per kernel family), start together so that
+    kernel instances see their first launch from racing threads; every thread's scores are bit-equal to the same call made
+    alone afterwards, and each thread reads its own error text (include/evdr.h, THREADING)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    libdir = os.path.join(ROOT, "efficient-visual-document-retrieval_amd")
+    exe = str(tmp_path / "cabi_threads")
+    subprocess.run([hipcc, "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cabi", "cabi_threads.cpp"),
+                    "-L", libdir, "-levdr", f"-Wl,-rpath,{libdir}", "-o", exe], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "cabi_threads OK" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 def test_the_ctypes_stub_printed_in_integration_md_runs():
     """INTEGRATION.md §2 shows the reference-side binding a maintainer would add (a ctypes stub around evdr_maxsim_fwd).  The block
     is taken out of the document, pointed at the built library and executed: it must score like the oracle (no doc rot)."""
