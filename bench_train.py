@@ -83,11 +83,12 @@ def time_mode(inp, kind: str, steps: int, warmup: int):
         # view of it; the host copy of the indices only keys the teacher-score cache
         lo = (i % EPOCH) * B
         idx, idx_dev = order[lo:lo + B], order_dev[lo:lo + B]
-        qpl = None
+        qpl = sct = None
         if use_epoch:
             if i % EPOCH == 0 or epoch[0] is None:                  # a new epoch: one gather + one split launch for all its batches
-                epoch[0] = driver.EpochBatches(Qall, qmall, order_dev, B)
+                epoch[0] = driver.EpochBatches(Qall, qmall, order_dev, B, teacher=teacher if cached else None)
             Qb, qmb, qpl = epoch[0].get(i % EPOCH)
+            sct = epoch[0].teacher_scores(i % EPOCH)
         else:
             Qb, qmb = Qall.index_select(0, idx_dev), qmall.index_select(0, idx_dev)
         if kind in ("resident", "cached"):
@@ -97,12 +98,12 @@ def time_mode(inp, kind: str, steps: int, warmup: int):
         if kind == "fused_cached_graph":                # teacher scores from the cache, student update replayed
             return float(graphed(Qb, qmb, teacher.scores(Qb, qmb, idx)).item())
         if kind in ("fused", "fused_cached"):
-            return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached" else None, qplanes=qpl)
+            return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached" else None, qplanes=qpl, sc_t=sct)
         if kind in ("fused_overlap", "fused_overlap_nosync"):   # student forward on a second stream beside the teacher forward
             return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, sync=kind == "fused_overlap", overlap=True)
         if kind in ("fused_nosync", "fused_cached_nosync"):     # loss stays on the device: no host sync inside the timed loop
             return driver.fused_train_one_step(Qb, qmb, teacher, student, 0.1, qidx=idx if kind == "fused_cached_nosync" else None,
-                                               sync=False, qplanes=qpl)
+                                               sync=False, qplanes=qpl, sc_t=sct)
         score = eager_maxsim if kind == "eager" else score_multi_vector_masked
         Psb = l2_normalize(param * pms.unsqueeze(-1))
         with torch.no_grad():

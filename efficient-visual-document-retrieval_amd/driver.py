@@ -402,7 +402,7 @@ def run(args) -> None:
             perm_dev = perm.to(Q_train.device) if Q_train.is_cuda else None
             # single-process fused steps: the epoch's batches are gathered and split into planes once per epoch (EpochBatches)
             use_epoch = student is not None and world == 1 and perm_dev is not None and args.q_batch * Q_train.shape[1] <= 2048
-            epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch) if use_epoch else None
+            epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch, teacher=teacher) if use_epoch else None
             t0, loss_sum, loss_cnt = time.time(), 0.0, 0
             # fused single-process steps leave their loss on the device; the host reads the pending ones when a line is due
             # (same numbers, same double-precision running sum in the same order: one sync per log line, not per step)
@@ -426,14 +426,15 @@ def run(args) -> None:
                     perm, cursor = torch.randperm(n_train, generator=gen), 0
                     perm_dev = perm.to(Q_train.device) if Q_train.is_cuda else None
                     if use_epoch:
-                        epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch)
+                        epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch, teacher=teacher)
                 idx = perm[cursor:cursor + args.q_batch]
                 qidx = idx if args.cache_teacher_scores else None
                 if perm_dev is not None:
                     idx = perm_dev[cursor:cursor + args.q_batch]
-                qpl_step = None
+                qpl_step = sct_step = None
                 if use_epoch:
                     Qb_step, qmb_step, qpl_step = epoch.get(cursor // args.q_batch)
+                    sct_step = epoch.teacher_scores(cursor // args.q_batch)
                 else:
                     Qb_step, qmb_step = Q_train.index_select(0, idx), qmask_train.index_select(0, idx)
                 cursor += args.q_batch
@@ -445,7 +446,7 @@ def run(args) -> None:
                                                      args.temp, shard_sizes, qidx=qidx)
                 elif student is not None:
                     loss_val = fused_train_one_step(Qb_step, qmb_step, teacher, student, args.temp, qidx=qidx,
-                                                    sync=not defer, qplanes=qpl_step)
+                                                    sync=not defer, qplanes=qpl_step, sc_t=sct_step)
                 else:
                     loss_val = train_one_step(Qb_step, qmb_step, teacher, pmask_t, Pbar_param, pmask_s, opt,
                                               temp=args.temp, qidx=qidx)
@@ -499,12 +500,22 @@ class EpochBatches:
     its teacher forward: 3 launches (~18 us of mostly launch latency on the step's critical path) become views.
     Costs one gathered fp32 copy of the query set plus its planes (2 x 16 KiB per 32-token query)."""
 
-    def __init__(self, Q: torch.Tensor, qmask: torch.Tensor, perm: torch.Tensor, batch: int, planes: bool = True):
+    def __init__(self, Q: torch.Tensor, qmask: torch.Tensor, perm: torch.Tensor, batch: int, planes: bool = True,
+                 teacher: Optional["TeacherScorer"] = None):
         self.batch = int(batch)
         self.Q = Q.index_select(0, perm)
         self.qmask = qmask.index_select(0, perm)
         self.n = int(self.Q.shape[0])
         self.planes = ops.split_f32_segments(self.Q, self.batch) if (planes and self.Q.is_cuda and self.n) else None
+        # a teacher whose score cache is complete (every pseudo-query scored once: from the second epoch on): the epoch's rows
+        # of it in batch order, one gather per epoch instead of one per step
+        self.sc_t = None
+        if teacher is not None and teacher.cache is not None and teacher.have is not None and bool(teacher.have.all()):
+            self.sc_t = teacher.cache.index_select(0, perm.to(teacher.cache.device))
+
+    def teacher_scores(self, i: int) -> Optional[torch.Tensor]:
+        """Cached teacher scores (B, N) of batch i, or None (no complete cache: score the batch)."""
+        return None if self.sc_t is None else self.sc_t[i * self.batch:(i + 1) * self.batch]
 
     def __len__(self) -> int:
         return (self.n + self.batch - 1) // self.batch
@@ -681,7 +692,8 @@ class GraphedStep:
 
 
 def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStudent, temp: float,
-                         qidx: Optional[torch.Tensor] = None, sync: bool = True, overlap: bool = False, qplanes=None):
+                         qidx: Optional[torch.Tensor] = None, sync: bool = True, overlap: bool = False, qplanes=None,
+                         sc_t: Optional[torch.Tensor] = None):
     """One fused update.  sync=True returns float(loss) like the reference's train_one_step (one host wait per step, for the
     loss only: the parameter update may still be running when it returns -- later work on the stream is ordered behind it);
     sync=False returns the loss as a device scalar and leaves the stream running, so that the host queues the next step
@@ -690,7 +702,8 @@ def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStuden
     loss waits for both).  Measured on MI355X (profiles/r03_experiments.txt): 0.4625 ms per step against 0.438 -- SLOWER.
     Both kernels fill the chip with one 256-register workgroup per CU that takes most of the LDS, so workgroups of the two
     launches cannot share a CU and only trade places, and the events cost host time; kept as an option for the A/B only.
-    `qplanes`: the batch's (planes, absmax word) when they exist already (EpochBatches: split once per epoch)."""
+    `qplanes`: the batch's (planes, absmax word) when they exist already (EpochBatches: split once per epoch).
+    `sc_t`: the batch's teacher scores when they exist already (EpochBatches.teacher_scores: rows of a complete cache)."""
     device = student.x.device
     Qb = Qb.to(device, non_blocking=True).float()
     qmb = qmb.to(device, non_blocking=True)
@@ -709,7 +722,8 @@ def fused_train_one_step(Qb, qmb, teacher: "TeacherScorer", student: FusedStuden
             student._ev_out.record(student._side)
         for t in (Qb, qmb, qplanes[0], qplanes[1]):                  # made on the main stream, read on the side stream
             t.record_stream(student._side)
-    sc_t = teacher.scores(Qb, qmb, qidx, qplanes=qplanes)
+    if sc_t is None:
+        sc_t = teacher.scores(Qb, qmb, qidx, qplanes=qplanes)
     if overlap:
         main.wait_event(student._ev_out)
         for t in scored:                                             # made on the side stream, read on the main stream

@@ -346,6 +346,25 @@ def test_epoch_batches_give_the_per_step_batches_and_planes_bit_for_bit(golden):
     torch.cuda.synchronize()
     assert torch.equal(b.x, a.x) and torch.equal(b.exp_avg, a.exp_avg) and torch.equal(b.exp_avg_sq, a.exp_avg_sq)
 
+    # cached teacher scores: handed out per epoch only once the cache is complete, and then the cache's own rows
+    tc = driver.TeacherScorer(l2_normalize(Pt * pmt.unsqueeze(-1)).to(dev), pmt.to(dev), cache_size=n)
+    assert driver.EpochBatches(Qn, qm, perm, B, teacher=tc).teacher_scores(0) is None
+    rows = {}
+    for i in range(len(eb)):
+        idx = perm[i * B:(i + 1) * B]
+        rows[i] = tc.scores(Qn.index_select(0, idx), qm.index_select(0, idx), idx.cpu()).clone()
+    ec = driver.EpochBatches(Qn, qm, perm, B, teacher=tc)
+    c, d = (driver.FusedStudent(Pbar0.to(dev), pms.to(dev), lr=hp["lr"], weight_decay=hp["wd"]) for _ in range(2))
+    for i in range(len(ec)):
+        assert torch.equal(ec.teacher_scores(i), rows[i])
+        idx = perm[i * B:(i + 1) * B]
+        Qi, qi, qpl = ec.get(i)
+        lc = driver.fused_train_one_step(Qi, qi, tc, c, hp["temp"], qidx=idx.cpu())
+        ld = driver.fused_train_one_step(Qi, qi, tc, d, hp["temp"], qplanes=qpl, sc_t=ec.teacher_scores(i))
+        assert lc == ld
+    torch.cuda.synchronize()
+    assert torch.equal(c.x, d.x)
+
 
 def test_two_graphed_steps_of_one_batch_size_captured_before_either_replays(golden):
     """the loss workspace (row losses + ticket word) of the one-launch InfoNCE kernel is owned by the student and
