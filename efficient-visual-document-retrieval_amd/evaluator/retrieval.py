@@ -48,6 +48,8 @@ _PREPARED_MAX_BYTES = 32 << 30         # of prepared planes in total (they are a
 
 def forget_prepared() -> None:
     _PREPARED.clear()
+    _QPLANES.clear()
+    ops._DERIVED.clear()
 
 
 def _tensor_key(t: Optional[torch.Tensor]):
@@ -70,7 +72,9 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
     if Pw.dtype == torch.bfloat16:                     # scored as they are: only the packed masks and the non-finite scan are kept
         planes, amax = Pw.contiguous()[None], None
     else:
-        planes, amax = ops.split_f32(Pw)
+        # pages that came out of this package's l2_normalize bring their planes along (ops.planes_of); others are split here
+        made = ops.planes_of(P) if (Pw is P and P.dtype == torch.float32) else None
+        planes, amax = made if made is not None else ops.split_f32(Pw)
     tilemask, pageflags = ops.pack_pmask(pmask, P.shape[0], P.shape[1], P.device)
     ops.flag_nonfinite(planes[0], pmask, pageflags)
     prep = (planes, amax, tilemask, pageflags)
@@ -81,6 +85,21 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
         while len(_PREPARED) > _PREPARED_MAX or sum(e[3] for e in _PREPARED.values()) > _PREPARED_MAX_BYTES:
             _PREPARED.popitem(last=False)
     return prep
+
+
+_QPLANES: list = []                    # [(weakref(Q), key, (planes, absmax word))]: the last fp32 query batch that was split
+
+
+def _query_planes(Q: torch.Tensor):
+    """fp16 hi/lo planes of an fp32 query batch.  The reference's step scores ONE batch twice in a row -- against the teacher
+    and against the student (mainv2_iter_distill_infonce.py:283,286) -- so the last batch's planes are kept while that tensor is
+    alive and unwritten (key as for the prepared pages)."""
+    key = _tensor_key(Q)
+    if _QPLANES and _QPLANES[0][1] == key and _QPLANES[0][0]() is not None:
+        return _QPLANES[0][2]
+    made = ops.split_f32(Q)
+    _QPLANES[:] = [(weakref.ref(Q, lambda _r: _QPLANES.clear() if (_QPLANES and _QPLANES[0][1] == key) else None), key, made)]
+    return made
 
 
 # ------------------------------------------------------------------------------------------------
@@ -102,11 +121,24 @@ class _MaxSimMasked(torch.autograd.Function):
         if frozen:
             # frozen pages: mask packing, the non-finite scan and (fp32) the plane split are done once per tensor
             planes, amax, tilemask, pageflags = _prepared_pages(P_caller, pmask)
-            qplanes, qamax = (Q.contiguous()[None], None) if both_bf16 else ops.split_f32(Q)
+            qplanes, qamax = (Q.contiguous()[None], None) if both_bf16 else _query_planes(Q)
             out, arg = ops.maxsim_forward_prepared(qplanes, qamax, planes, amax, qmask, tilemask, pageflags,
                                                    want_argmax=need_dq)
         else:
-            out, arg = ops.maxsim_forward(Q, P, qmask, pmask, want_argmax=need_dp or need_dq)
+            # trainable pages that came out of this package's l2_normalize (the reference's Psb, :279) bring their planes along
+            derived = None
+            if (P_caller is P and P.is_cuda and P.dtype == torch.float32 and Q.dtype == torch.float32 and P.dim() == 3 and Q.dim() == 3
+                    and P.shape[-1] == ops.D and Q.shape[-1] == ops.D and P.shape[0] > 0 and 0 < P.shape[1] <= 65535
+                    and Q.shape[0] > 0 and 0 < Q.shape[1] <= 65535):
+                derived = ops.planes_of(P)
+            if derived is not None:
+                planes, amax = derived
+                tilemask, pageflags = ops.pack_pmask(pmask, P.shape[0], P.shape[1], P.device)
+                ops.flag_nonfinite(planes[0], pmask, pageflags)
+                qplanes, qamax = _query_planes(Q)
+                out, arg = ops.maxsim_forward_prepared(qplanes, qamax, planes, amax, qmask, tilemask, pageflags, want_argmax=True)
+            else:
+                out, arg = ops.maxsim_forward(Q, P, qmask, pmask, want_argmax=need_dp or need_dq)
         if need_dp or need_dq:
             ctx.save_for_backward(Q.detach(), P.detach() if need_dq else None, qmask, pmask, arg)
             ctx.p_shape, ctx.p_dtype, ctx.q_dtype = tuple(P.shape), P.dtype, Q.dtype

@@ -5,6 +5,9 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import collections
+import weakref
+
 import torch
 
 from . import _lib as L
@@ -349,8 +352,10 @@ def infonce_distill(score_s: torch.Tensor, score_t: torch.Tensor, temperature: f
     return loss, grad
 
 
-def l2norm_forward(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
-    """A4 fused with the row mask: y = m*x / (||m*x|| + eps) over the last (128-wide) dim; returns (y, norms)."""
+def l2norm_forward(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float, want_planes: bool = False):
+    """A4 fused with the row mask: y = m*x / (||m*x|| + eps) over the last (128-wide) dim; returns (y, norms), with
+    `want_planes` (y, norms, planes, absmax word): the same launch also leaves y as the scorer's fp16 hi/lo planes
+    (`l2norm_split`'s format, constant scale 2^14 since |y| <= 1), so that scoring y needs no absmax + split passes."""
     dev = _require_cuda(x)
     if x.shape[-1] != D or x.dtype != torch.float32:
         raise RuntimeError("l2norm kernel needs fp32 rows of width 128")
@@ -360,10 +365,45 @@ def l2norm_forward(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float)
     y = torch.empty_like(xc)
     norm = torch.empty(xc.shape[:-1], dtype=torch.float32, device=dev)
     m = _mask_u8(rowmask, xc.shape[:-1], dev)
+    if want_planes:
+        planes = torch.empty((2,) + tuple(xc.shape), dtype=torch.float16, device=dev)
+        amax = torch.empty((1,), dtype=torch.int32, device=dev)
+        with L.on(dev):
+            L.check(lib.evdr_l2norm_fwd_split(L.ptr(xc), L.ptr(m), rows, D, float(eps), L.ptr(y), L.ptr(norm), L.ptr(planes), L.ptr(amax),
+                                              None, 1, L.current_stream_handle(dev)))
+        return y, norm, planes, amax
     with L.on(dev):
         L.check(lib.evdr_l2norm_fwd(L.ptr(xc), L.ptr(m), rows, D, float(eps), L.ptr(y), L.ptr(norm),
                                     L.current_stream_handle(dev)))
     return y, norm
+
+
+# ---- planes that were made together with an fp32 tensor (l2_normalize's output: utils/preprocess_data.py) -----------------
+# The reference's step scores Psb = l2_normalize(Pbar * pmask) right after making it (mainv2_iter_distill_infonce.py:279,286):
+# the normalise kernel leaves Psb's planes behind here, keyed on the tensor (address, layout, autograd version) and alive
+# only as long as the tensor is; the scorer picks them up instead of running absmax + split over Psb again.
+_DERIVED: "collections.OrderedDict" = collections.OrderedDict()
+_DERIVED_MAX = 8
+
+
+def tensor_key(t: torch.Tensor):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t.device.index, t._version)
+
+
+def remember_planes(y: torch.Tensor, planes: torch.Tensor, amax: torch.Tensor) -> None:
+    key = tensor_key(y)
+    _DERIVED[key] = (weakref.ref(y, lambda _r, key=key: _DERIVED.pop(key, None)), planes, amax)
+    while len(_DERIVED) > _DERIVED_MAX:
+        _DERIVED.popitem(last=False)
+
+
+def planes_of(t: torch.Tensor):
+    """(planes, absmax word) made together with `t` (same storage, layout and autograd version: any in-place torch write
+    since then changes the key), or None."""
+    hit = _DERIVED.get(tensor_key(t))
+    if hit is None or hit[0]() is None:
+        return None
+    return hit[1], hit[2]
 
 
 def l2norm_split(x: torch.Tensor, rowmask: Optional[torch.Tensor], eps: float,

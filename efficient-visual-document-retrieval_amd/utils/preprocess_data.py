@@ -21,11 +21,19 @@ def load_npz(path: str):
 
 class _L2NormMasked(torch.autograd.Function):
     """y = m * x / (||m * x|| + eps) on the HIP kernels (evdr_l2norm_fwd / _bwd); m = optional per-row mask."""
+    last_planes = None          # (address of y, planes, absmax word) of the forward that just ran: handed to _normalized()
 
     @staticmethod
     def forward(ctx, x, rowmask, eps):
         from .. import ops
-        y, norm = ops.l2norm_forward(x, rowmask, eps)
+        if x.dim() == 3:
+            # page-shaped input (N, L, 128): the launch also leaves y as the scorer's fp16 hi/lo planes; _normalized() below
+            # hangs them on the returned tensor, so that score_multi_vector_masked(Q, y, ...) -- the very next call in the
+            # reference's step, mainv2_iter_distill_infonce.py:279,286 -- runs no absmax + split passes over y
+            y, norm, planes, amax = ops.l2norm_forward(x, rowmask, eps, want_planes=True)
+            _L2NormMasked.last_planes = (y.data_ptr(), planes, amax)
+        else:
+            y, norm = ops.l2norm_forward(x, rowmask, eps)
         if ctx.needs_input_grad[0]:
             ctx.save_for_backward(x, rowmask, norm)
             ctx.eps = eps
@@ -42,6 +50,17 @@ def _kernel_ok(x: torch.Tensor) -> bool:
     return x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.shape[-1] == 128 and x.numel() > 0
 
 
+def _normalized(x: torch.Tensor, rowmask, eps: float) -> torch.Tensor:
+    from .. import ops
+    _L2NormMasked.last_planes = None
+    y = _L2NormMasked.apply(x, rowmask, float(eps))
+    made = _L2NormMasked.last_planes
+    _L2NormMasked.last_planes = None
+    if made is not None and made[0] == y.data_ptr():
+        ops.remember_planes(y, made[1], made[2])          # alive as long as y is, dropped by any in-place write to y
+    return y
+
+
 def l2_normalize(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     """x / (||x||_2 + eps) over the last dim -- eps is ADDED to the norm, zero rows stay exactly zero and get
     the subgradient 0 through the norm (utils/preprocess_data.py:8-9; applied to Pbar*pmask every step,
@@ -49,7 +68,7 @@ def l2_normalize(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     training step) run on one fused HIP kernel each way; anything else (host-side preprocessing on the CPU, other
     widths) is the same formula in torch."""
     if _kernel_ok(x):
-        return _L2NormMasked.apply(x, None, float(eps))
+        return _normalized(x, None, eps)
     return x / (torch.linalg.vector_norm(x, ord=2, dim=-1, keepdim=True) + eps)
 
 
@@ -57,7 +76,7 @@ def normalize_masked(x: torch.Tensor, rowmask: torch.Tensor, eps: float = 1e-12)
     """l2_normalize(x * rowmask[..., None]) in ONE kernel each way (the `Pbar_param * pmask` multiply of
     mainv2_iter_distill_infonce.py:279 fused into the normalisation); same values and gradients."""
     if _kernel_ok(x):
-        return _L2NormMasked.apply(x, rowmask, float(eps))
+        return _normalized(x, rowmask, eps)
     return l2_normalize(x * rowmask.unsqueeze(-1).to(x.dtype), eps)
 
 

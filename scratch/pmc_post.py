@@ -19,7 +19,7 @@ rd, wr = 2 * m("FETCH_SIZE") * 1024, m("WRITE_SIZE") * 1024
 wc = m("SQ_WAVE_CYCLES")
 shares = {"active": m("SQ_ACTIVE_INST_ANY") / wc,
           "issue_stall": m("SQ_WAIT_INST_ANY") / wc, "parked": m("SQ_WAIT_ANY") / wc}
-out = {"round": int(tag[1:]), "workload": f"bench.py --steps 1 --no-other-regimes ({line['config']['queries_per_step']} queries x {line['config']['pages']} pages), kernel {kernel}",
+out = {"round": int("".join(ch for ch in tag[1:] if ch.isdigit())), "workload": f"bench.py --steps 1 --no-other-regimes ({line['config']['queries_per_step']} queries x {line['config']['pages']} pages), kernel {kernel}",
        "kernel_ms_under_pmc": t_sq1 * 1e3, "effective_clock_ghz": clock, "mfma_busy_frac": busy,
        "lds_bank_conflict_cycles": m("SQ_LDS_BANK_CONFLICT"), "hbm_bytes_per_launch": rd + wr, "hbm_read_bytes": rd, "hbm_write_bytes": wr,
        "derivation": "clock = GRBM_GUI_ACTIVE/8/time; busy = SQ_VALU_MFMA_BUSY_CYCLES/1024/(GRBM_GUI_ACTIVE/8); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
@@ -30,6 +30,6 @@ traffic = {"queries": line["config"]["queries_per_step"], "pages_per_gpu": line[
            "method": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/{tag}_pmc_summary.json, scratch/pmc.sh); FETCH_SIZE is in KB and reads 1/2 of "
                      "wide 16-B/lane streaming reads on gfx950 (MI355X_MICROARCH.md 'HBM'), so bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; Infinity-Cache hits are included "
                      "in these fabric-side counters",
-           "fetch_size_kb": m("FETCH_SIZE"), "write_size_kb": m("WRITE_SIZE"), "round": int(tag[1:]), "kernel": kernel}
+           "fetch_size_kb": m("FETCH_SIZE"), "write_size_kb": m("WRITE_SIZE"), "round": int("".join(ch for ch in tag[1:] if ch.isdigit())), "kernel": kernel}
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "counters"}, indent=1))

@@ -403,3 +403,64 @@ def test_large_teacher_corpus_streams_non_temporally_and_scores_the_same_bits():
         assert torch.equal(got, other)
         want = O.maxsim_masked(Q[:4].cpu(), P[:24].cpu(), qm[:4].cpu(), pm[:24].cpu())
         np.testing.assert_allclose(got[:4, :24].cpu().numpy(), want.numpy(), atol=1e-4, rtol=0)
+
+
+def test_pages_from_l2_normalize_bring_their_planes_to_the_scorer():
+    """The reference's step scores Psb = l2_normalize(Pbar * pmask[..., None]) right after making it
+    (mainv2_iter_distill_infonce.py:279,286).  The drop-in l2_normalize leaves Psb's fp16 hi/lo planes behind (same launch) and
+    score_multi_vector_masked picks them up -- no absmax + split passes over Psb -- for as long as Psb is alive and unwritten.
+    Scores, arg-max routing (dP through the normalisation and the mask) and the NaN rules are the reference's."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import ops
+    from evdr_amd.evaluator.retrieval import score_multi_vector_masked
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    g = torch.Generator().manual_seed(77)
+    nq, lq, npg, lp = 9, 20, 14, 70
+    Q = torch.nn.functional.normalize(torch.randn(nq, lq, 128, generator=g), dim=-1)
+    X = torch.randn(npg, lp, 128, generator=g)
+    qm = torch.rand(nq, lq, generator=g) > 0.2
+    pm = torch.rand(npg, lp, generator=g) > 0.25
+    pm[4] = False
+    gs = torch.randn(nq, npg, generator=g)
+
+    def reference(Xc):
+        Xo = Xc.clone().requires_grad_(True)
+        so = O.maxsim_masked(Q, O.l2_normalize(Xo * pm.unsqueeze(-1)), qm, pm)
+        (so * gs).sum().backward()
+        return so.detach(), Xo.grad
+
+    def ours(Xc, touch=False):
+        Xd = Xc.clone().to(DEV).requires_grad_(True)
+        Psb = l2_normalize(Xd * pm.to(DEV).unsqueeze(-1))
+        assert ops.planes_of(Psb) is not None
+        if touch:
+            with torch.no_grad():
+                Psb.mul_(1.0)                                          # an in-place write: the planes no longer belong to Psb
+            assert ops.planes_of(Psb) is None
+        s = score_multi_vector_masked(Q.to(DEV), Psb, qm.to(DEV), pm.to(DEV))
+        (s * gs.to(DEV)).sum().backward()
+        return s.detach().cpu(), Xd.grad.cpu()
+
+    so, go = reference(X)
+    for touch in (False, True):
+        s, gx = ours(X, touch)
+        np.testing.assert_allclose(s.numpy(), so.numpy(), atol=1e-4, rtol=0)
+        np.testing.assert_allclose(gx.numpy(), go.numpy(), atol=2e-6, rtol=1e-5)
+    # a NaN in a VALID patch poisons its page's column; a NaN that the script's own multiply leaves in a MASKED row (NaN * 0)
+    # is replaced by -1e4 before the max in the reference (evaluator/retrieval.py:198) and changes nothing
+    Xn = X.clone()
+    v = int(pm[2].nonzero()[0])
+    m = int((~pm[6]).nonzero()[0])
+    Xn[2, v, 5] = float("nan")
+    Xn[6, m, 9] = float("nan")
+    with torch.no_grad():
+        Psb = l2_normalize(Xn.to(DEV) * pm.to(DEV).unsqueeze(-1))
+        s = score_multi_vector_masked(Q.to(DEV), Psb, qm.to(DEV), pm.to(DEV)).cpu()                 # frozen path, derived planes
+    Xg = Xn.clone().to(DEV).requires_grad_(True)
+    sg = score_multi_vector_masked(Q.to(DEV), l2_normalize(Xg * pm.to(DEV).unsqueeze(-1)), qm.to(DEV), pm.to(DEV)).detach().cpu()
+    want = O.maxsim_masked(Q, O.l2_normalize(Xn * pm.unsqueeze(-1)), qm, pm)
+    for got in (s, sg):
+        _check_nan_positions(got, want, "l2_normalize -> scorer")
+        assert torch.isnan(got[:, 2]).all() and not torch.isnan(got[:, 6]).any()
+        ok = ~torch.isnan(want)
+        np.testing.assert_allclose(got[ok].numpy(), want[ok].numpy(), atol=1e-4, rtol=0)
