@@ -313,7 +313,7 @@ def main():
             ranks_seen = int(probe.item())
 
     import evdr_amd  # noqa: F401
-    from evdr_amd.corpus import PageCorpus, ShardedRetriever, shard_range
+    from evdr_amd.corpus import PageCorpus, ShardedRetriever, gather_candidates, shard_range
     from evdr_amd.evaluator.retrieval import CustomRetrievalEvaluator
     from evdr_amd.evaluator.metrics import results_from_topk
 
@@ -338,6 +338,12 @@ def main():
             barrier()
         torch.cuda.synchronize()
 
+    if multi:
+        # setup, like the corpus: the data group's FIRST all-gather (RCCL sets its rings / channels up lazily, per collective kind)
+        # happens here, on a dummy message of the step's own shape, so that it can never land in the timed region -- also with --warmup 0
+        gather_candidates(torch.zeros((args.queries, args.topk), dtype=torch.float32, device=dev),
+                          torch.zeros((args.queries, args.topk), dtype=torch.int32, device=dev), group)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     corpus.score_events = []        # the dominant kernel of every TIMED step bracketed by HIP events on its launch stream
@@ -363,7 +369,7 @@ def main():
     # phases by HIP events on the launch stream, the exchange by a host timer between a barrier and the arrival of the
     # gathered candidates; per phase the mean over `reps` on this rank, then the max over ranks
     from evdr_amd import ops as _ops
-    from evdr_amd.corpus import gather_candidates, merge_candidates
+    from evdr_amd.corpus import merge_candidates
 
     def all_ranks_ok(ok: bool) -> bool:
         """Control-plane agreement (gloo default group): True only if EVERY rank says ok -- taken before a section that holds
