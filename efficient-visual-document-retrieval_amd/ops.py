@@ -125,7 +125,11 @@ def split_f32_segments(x: torch.Tensor, seg: int) -> Tuple[torch.Tensor, torch.T
     if n:
         lib = L.load()
         with L.on(dev):
-            L.check(lib.evdr_split_f32_segments(L.ptr(xc), n * per, seg * per, L.ptr(planes), L.ptr(amax), L.current_stream_handle(dev)))
+            for s0 in range(0, nseg, 65535):                       # one launch covers at most 65535 segments (grid limit)
+                s1 = min(nseg, s0 + 65535)
+                rows = (min(n, s1 * seg) - s0 * seg) * per
+                L.check(lib.evdr_split_f32_segments(xc.data_ptr() + s0 * seg * per * D * 4, rows, seg * per, planes[s0:].data_ptr(),
+                                                    amax[s0:].data_ptr(), L.current_stream_handle(dev)))
     return planes, amax
 
 

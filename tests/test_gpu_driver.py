@@ -330,6 +330,13 @@ def test_epoch_batches_give_the_per_step_batches_and_planes_bit_for_bit(golden):
         assert torch.equal(am, wam)
     with pytest.raises(ValueError):
         ops.split_f32_segments(Q, 65)                              # 65 x 32 rows: more than one workgroup's segment
+    # more segments than one launch's grid holds (65535): the wrapper cuts the job into several launches
+    many = torch.randn(70000, 1, 128, generator=torch.Generator(device=dev).manual_seed(3), device=dev) * torch.logspace(-3, 3, 70000, device=dev)[:, None, None]
+    pl_m, am_m = ops.split_f32_segments(many, 1)
+    for sidx in (0, 1, 65534, 65535, 65536, 69999):
+        got_pl, got_am = ops.segment_planes(pl_m, am_m, sidx, many[sidx:sidx + 1].shape)
+        want_pl, want_am = ops.split_f32(many[sidx:sidx + 1])
+        assert torch.equal(got_pl.view(torch.int16), want_pl.view(torch.int16)) and torch.equal(got_am, want_am), sidx
 
     Qb, qmb, Pt, pmt, Pbar0, pms, hp = R.train_case("b32n128")
     teacher = driver.TeacherScorer(l2_normalize(Pt * pmt.unsqueeze(-1)).to(dev), pmt.to(dev))
