@@ -9,6 +9,7 @@ import evdr_amd
 from evdr_amd import _lib as _L
 if os.environ.get("EVDR_FUZZ_LIB"): _L.LIB_PATH = os.path.join(_L.PKG_DIR, os.environ["EVDR_FUZZ_LIB"])     # e.g. libevdr_sentinel.so (scratch-only switch)
 from evdr_amd import ops
+if os.environ.get("EVDR_FUZZ_VARIANT"): _L.load().evdr_debug_set_fwd_variant(int(os.environ["EVDR_FUZZ_VARIANT"]))   # e.g. 33: the nt stream of the fp16-plane forward forced on (scratch-only switch)
 from oracle import maxsim_oracle as O
 import test_gpu_random_sweep as T
 dev = "cuda:0"; s0, n = int(sys.argv[1]), int(sys.argv[2]); bad = 0
