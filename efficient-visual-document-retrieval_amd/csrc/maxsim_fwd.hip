@@ -81,6 +81,7 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
         qw = (p.nq > 8) ? 2 : 1;
 #ifdef EVDR_EXPERIMENT
         if (variant == 13) qw = 2;          // dispatched as one query per wave on 4-wave workgroups (see maxsim_fwd16.hip)
+        if (variant == 35) qw = 1;          // A/B: one query per wave (8 per workgroup, twice the query groups, half the prologue bytes per workgroup)
 #endif
     }
     // HBM-bound launches (a handful of queries) want the refill in flight as early as possible: +3 % at 1-4 queries;
