@@ -874,6 +874,18 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                             const int q = 4 * (h + off) / (2 * ST);
                             return 3 - (q > 3 ? 3 : q);
                         };
+                        // in-block refill: which of this wave's G pieces of the NEXT stage go out during tile `ti` of this one.
+                        // EVDR_REFILL_FRONT = 0: G / ST per tile, evenly over the block; = 1 (A/B build): twice as many per tile over the
+                        // FIRST half of the block, so that the last piece has half a block -- not one tile -- to land before the hand-over
+                        auto refill_lo = [&](int ti) {
+#if defined(EVDR_REFILL_FRONT) && EVDR_REFILL_FRONT == 1
+                            const int v = 2 * ti * (G / ST);
+#else
+                            const int v = ti * (G / ST);
+#endif
+                            return v < G ? v : G;
+                        };
+                        auto refill_hi = [&](int ti) { return refill_lo(ti + 1); };
                         auto set_prio = [&](int h) {
                             if constexpr (BAL) {
                                 const int pr = prio_at(h);
@@ -906,7 +918,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                                 if constexpr (SP) {
                                     if ((h & 1) == 0) {
 #pragma unroll
-                                        for (int e = 0; e < G / ST; ++e) issue_piece(nbase, nt0, 0, 0, nslot, (h >> 1) * (G / ST) + e, std::true_type{});
+                                        for (int i = refill_lo(h >> 1); i < refill_hi(h >> 1); ++i) issue_piece(nbase, nt0, 0, 0, nslot, i, std::true_type{});
                                     }
                                 }
                             }
@@ -945,7 +957,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                                 if constexpr (SP) {
                                     if ((h & 1) == 0) {
 #pragma unroll
-                                        for (int pl = 0; pl < G / ST; ++pl) issue_piece(nbase, nt0, 0, 0, nslot, (h >> 1) * (G / ST) + pl, std::true_type{});
+                                        for (int i = refill_lo(h >> 1); i < refill_hi(h >> 1); ++i) issue_piece(nbase, nt0, 0, 0, nslot, i, std::true_type{});
                                     }
                                 }
 #pragma unroll
