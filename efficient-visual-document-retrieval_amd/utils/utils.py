@@ -148,13 +148,24 @@ def save_compressed_npz(save_path, docid, documents_obj, doc_attnmask_obj, doc_i
     """Write a `best_*.npz`: object arrays `docid`, `documents` and, when given, `doc_attnmask` / `doc_imgmask`, plus the
     run's `meta` dict as a 0-d object array."""
     target = os.fspath(save_path)
+    _write_npz(target, docid, documents_obj, doc_attnmask_obj, doc_imgmask_obj, meta)
+    print(f"[save] {target}")
+
+
+def _write_npz(target: str, docid, documents_obj, doc_attnmask_obj, doc_imgmask_obj, meta: Dict[str, Any], atomic: bool = False):
+    """The file of `save_compressed_npz`; atomic=True writes `<target>.tmp.npz` first and renames it over the target, so that a
+    reader (or a crash) never meets a half-written checkpoint (driver.CheckpointWriter)."""
     os.makedirs(os.path.dirname(target) or ".", exist_ok=True)
     fields = [("docid", docid), ("documents", documents_obj), ("doc_attnmask", doc_attnmask_obj),
               ("doc_imgmask", doc_imgmask_obj)]
     arrays = {key: _as_object_array(val) for key, val in fields if val is not None}
     arrays["meta"] = np.array(meta, dtype=object)
-    np.savez_compressed(target, **arrays)
-    print(f"[save] {target}")
+    if atomic:
+        tmp = target + ".tmp.npz"
+        np.savez_compressed(tmp, **arrays)
+        os.replace(tmp, target)
+    else:
+        np.savez_compressed(target, **arrays)
 
 
 def align_by_docid(docid_ref, docid_other, *arrays_to_perm) -> Tuple[Tuple[Optional[np.ndarray], ...], bool]:
