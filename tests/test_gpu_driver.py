@@ -131,6 +131,29 @@ def test_driver_fused_step_flag(tmp_path):
         np.testing.assert_allclose(recs["batched"][st]["train/avg_loss"], recs["every"][st]["train/avg_loss"], rtol=1e-5)
 
 
+def test_driver_reads_the_next_dataset_ahead(tmp_path):
+    """Two datasets in one run: while the first trains, the second one's dump files are read by the loader thread; both come out
+    like single-dataset runs (same logged losses, the summary line of the log contract)."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import driver
+    write_synthetic_dataset(tmp_path)
+    m = json.loads((tmp_path / "map.json").read_text())
+    m["synth2"] = dict(m["synth"])                                     # a second name for the same dumps
+    (tmp_path / "map2.json").write_text(json.dumps(m))
+    out = tmp_path / "results_two"
+    driver.main(["--datasets", "synth", "synth2", "--mapping_json", str(tmp_path / "map2.json"), "--query_root", str(tmp_path),
+                 "--teacher_root", str(tmp_path), "--init_root", str(tmp_path), "--mfs", "4", "--out_root", str(out), "--name", "run",
+                 "--max_steps", "8", "--eval_every", "8", "--print_every", "1", "--q_batch", "32", "--fused_step"])
+    losses = {}
+    for name in ("synth", "synth2"):
+        d = out / "run" / "mf4" / name
+        assert (d / "config.json").exists() and not list(d.glob("*.tmp.npz"))
+        lines = (d / "train.log").read_text().splitlines()
+        assert any("summary/best_ndcg5" in ln for ln in lines)
+        losses[name] = [json.loads(ln[ln.index("{"):])["train/loss"] for ln in lines if '"train/loss"' in ln]
+    assert len(losses["synth"]) == 8 and losses["synth"] == losses["synth2"]
+
+
 def test_driver_step_matches_oracle():
     """driver.train_one_step with the resident TeacherScorer == the oracle's restatement of the reference step."""
     import evdr_amd  # noqa: F401
