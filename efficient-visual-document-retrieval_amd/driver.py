@@ -416,13 +416,14 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
 
     def read_dataset(name: str):
         pt = mapping[name]
-        return load_query_payload(f"{args.query_root}/{pt['pseudoQ']}"), load_payload(f"{args.teacher_root}/{pt['split_before']}")
+        inits = {f"mf{m}": load_init_payload(f"{args.init_root}/{pt[f'mf{m}']}") for m in args.mfs if f"mf{m}" in pt}   # a few tens of MB each
+        return load_query_payload(f"{args.query_root}/{pt['pseudoQ']}"), load_payload(f"{args.teacher_root}/{pt['split_before']}"), inits
 
     loader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="evdr-dataset-loader")
     ahead = {}
     for di, dataset in enumerate(args.datasets):
         paths = mapping[dataset]
-        q_payload, t_payload = ahead.pop(dataset).result() if dataset in ahead else read_dataset(dataset)
+        q_payload, t_payload, init_payloads = ahead.pop(dataset).result() if dataset in ahead else read_dataset(dataset)
         if di + 1 < len(args.datasets) and args.datasets[di + 1] not in ahead:
             ahead[args.datasets[di + 1]] = loader.submit(read_dataset, args.datasets[di + 1])
         docid_tr = t_payload["docid"]
@@ -455,7 +456,7 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
             key = f"mf{mf}"
             if key not in paths:
                 raise ValueError(f"Missing mapping for {dataset}:{key}")
-            init = load_init_payload(f"{args.init_root}/{paths[key]}")
+            init = init_payloads.pop(key)                            # read with the dataset's other files (read_dataset)
             Pbar_obj, attn_in, img_in = init["documents"], init["doc_attnmask"], init["doc_imgmask"]
             if init.get("docid") is not None:
                 (Pbar_obj, attn_in, img_in), ok = align_by_docid(_as_object_array(docid_tr), _as_object_array(init["docid"]),
