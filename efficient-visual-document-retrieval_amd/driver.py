@@ -58,8 +58,10 @@ class TeacherScorer:
         idx_host = qidx.detach().cpu().numpy().astype(np.int64)
         idx_dev = qidx.to(self.cache.device, non_blocking=True)
         if not self.have[idx_host].all():
-            self.cache[idx_dev] = self.corpus.score(Qb.float(), qmb, qplanes=qplanes)
+            sc = self.corpus.score(Qb.float(), qmb, qplanes=qplanes)
+            self.cache[idx_dev] = sc
             self.have[idx_host] = True
+            return sc                                       # the rows just written: no gather of them back out of the cache
         return self.cache[idx_dev]
 
 
@@ -510,9 +512,10 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
             # resident pseudo-queries: the epoch's permutation goes to the device once, a batch's indices are a view of it
             # (no index upload per step) and the rows come out with index_select (half the host cost of advanced indexing)
             perm_dev = perm.to(Q_train.device) if Q_train.is_cuda else None
-            # single-process fused steps: the epoch's batches are gathered and split into planes once per epoch (EpochBatches)
-            use_epoch = student is not None and world == 1 and perm_dev is not None and args.q_batch * Q_train.shape[1] <= 2048
-            epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch, teacher=teacher) if use_epoch else None
+            # single-process runs: the epoch's batches are gathered once per epoch and -- fused steps -- split into planes in one launch (EpochBatches)
+            # (the autograd path takes the gathered rows only: its scorer calls split the batch themselves)
+            use_epoch = world == 1 and perm_dev is not None and (student is None or args.q_batch * Q_train.shape[1] <= 2048)
+            epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch, planes=student is not None, teacher=teacher) if use_epoch else None
             t0, loss_sum, loss_cnt = time.time(), 0.0, 0
             # fused single-process steps leave their loss on the device; the host reads the pending ones when a line is due
             # (same numbers, same double-precision running sum in the same order: one sync per log line, not per step)
@@ -536,7 +539,7 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
                     perm, cursor = torch.randperm(n_train, generator=gen), 0
                     perm_dev = perm.to(Q_train.device) if Q_train.is_cuda else None
                     if use_epoch:
-                        epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch, teacher=teacher)
+                        epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch, planes=student is not None, teacher=teacher)
                 idx = perm[cursor:cursor + args.q_batch]
                 qidx = idx if args.cache_teacher_scores else None
                 if perm_dev is not None:
