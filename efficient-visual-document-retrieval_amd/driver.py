@@ -419,13 +419,17 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
     def read_dataset(name: str):
         pt = mapping[name]
         inits = {f"mf{m}": load_init_payload(f"{args.init_root}/{pt[f'mf{m}']}") for m in args.mfs if f"mf{m}" in pt}   # a few tens of MB each
-        return load_query_payload(f"{args.query_root}/{pt['pseudoQ']}"), load_payload(f"{args.teacher_root}/{pt['split_before']}"), inits
+        qp, tp = load_query_payload(f"{args.query_root}/{pt['pseudoQ']}"), load_payload(f"{args.teacher_root}/{pt['split_before']}")
+        # this rank's teacher pages padded to one (n, Lmax, 128) host tensor + mask here as well (pure copies: numpy releases the GIL)
+        lo_, hi_ = shard_range(len(tp["documents"]), rank, world)
+        host_pages = _shard_docs(tp["documents"], tp["doc_attnmask"], tp["doc_imgmask"], lo_, hi_, world, "cpu")
+        return qp, tp, inits, host_pages
 
     loader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="evdr-dataset-loader")
     ahead = {}
     for di, dataset in enumerate(args.datasets):
         paths = mapping[dataset]
-        q_payload, t_payload, init_payloads = ahead.pop(dataset).result() if dataset in ahead else read_dataset(dataset)
+        q_payload, t_payload, init_payloads, host_pages = ahead.pop(dataset).result() if dataset in ahead else read_dataset(dataset)
         if di + 1 < len(args.datasets) and args.datasets[di + 1] not in ahead:
             ahead[args.datasets[di + 1]] = loader.submit(read_dataset, args.datasets[di + 1])
         docid_tr = t_payload["docid"]
@@ -441,7 +445,8 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
         lo, hi = shard_range(n_pages, rank, world)
         shard_sizes = [shard_range(n_pages, r, world)[1] - shard_range(n_pages, r, world)[0] for r in range(world)] if world > 1 else None
         torch.cuda.reset_peak_memory_stats(device)
-        P_t_raw, pmask_t = _shard_docs(t_payload["documents"], t_payload["doc_attnmask"], t_payload["doc_imgmask"], lo, hi, world, device)
+        P_t_raw, pmask_t = host_pages[0].to(device), host_pages[1].to(device)       # padded on the host by read_dataset
+        del host_pages
         P_t_norm = l2_normalize(P_t_raw * pmask_t.unsqueeze(-1)).detach()
         n_train = Q_train.shape[0]
         stats = {"dataset": dataset, "rank": rank, "world": world, "n_pages": n_pages, "lo": lo, "hi": hi,
