@@ -519,7 +519,7 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
             perm_dev = perm.to(Q_train.device) if Q_train.is_cuda else None
             # single-process runs: the epoch's batches are gathered once per epoch and -- fused steps -- split into planes in one launch (EpochBatches)
             # (the autograd path takes the gathered rows only: its scorer calls split the batch themselves)
-            use_epoch = world == 1 and perm_dev is not None and (student is None or args.q_batch * Q_train.shape[1] <= 2048)
+            use_epoch = (world == 1 or student is not None) and perm_dev is not None and (student is None or args.q_batch * Q_train.shape[1] <= 2048)
             epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch, planes=student is not None, teacher=teacher) if use_epoch else None
             t0, loss_sum, loss_cnt = time.time(), 0.0, 0
             # fused single-process steps leave their loss on the device; the host reads the pending ones when a line is due
@@ -537,7 +537,7 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
                     pending.clear()
                     loss_val = vals[-1]
 
-            defer = student is not None and world == 1              # with or without TensorBoard: no host wait per step
+            defer = student is not None                             # fused steps (single process or page-sharded: the loss is the same number on every rank): no host wait per step
             loss_val = 0.0
             for step in range(1, args.max_steps + 1):
                 if cursor >= n_train:                               # epoch boundary: reshuffle (DataLoader(shuffle=True))
@@ -558,7 +558,8 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
                 cursor += args.q_batch
                 if world > 1 and student is not None:
                     loss_val = sharded_fused_train_one_step(Qb_step, qmb_step, teacher, student, args.temp,
-                                                           shard_sizes, qidx=qidx)
+                                                           shard_sizes, qidx=qidx, qplanes=qpl_step, sync=not defer,
+                                                           sc_t_local=sct_step)
                 elif world > 1:
                     loss_val = sharded_train_one_step(Qb_step, qmb_step, teacher, Pbar_param, pmask_s, opt,
                                                      args.temp, shard_sizes, qidx=qidx)
@@ -878,6 +879,26 @@ def gather_columns(block: torch.Tensor, sizes, group=None) -> torch.Tensor:
     return torch.cat([buf[r, :, : sizes[r]] for r in range(len(sizes))], dim=1)
 
 
+def gather_column_blocks(blocks, sizes, group=None):
+    """`gather_columns` of SEVERAL (B, n_local) blocks of this rank (teacher and student scores of one step) in ONE all-gather:
+    the blocks ride stacked in one (k, B, max(sizes)) message per rank.  -> a list of full (B, N) tensors, the same on every rank."""
+    import torch.distributed as dist
+    k, b, nmax = len(blocks), blocks[0].shape[0], max(sizes)
+    dev = blocks[0].device
+    msg = torch.zeros((k, b, nmax), dtype=torch.float32, device=dev)
+    for i, blk in enumerate(blocks):
+        msg[i, :, : blk.shape[1]] = blk
+    if dist.get_backend(group) == "gloo" and msg.is_cuda:
+        buf = torch.empty((len(sizes) * k, b, nmax), dtype=torch.float32)
+        dist.all_gather_into_tensor(buf, msg.cpu(), group=group)
+        buf = buf.to(dev)
+    else:
+        buf = torch.empty((len(sizes) * k, b, nmax), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(buf, msg, group=group)
+    buf = buf.view(len(sizes), k, b, nmax)
+    return [torch.cat([buf[r, i, :, : sizes[r]] for r in range(len(sizes))], dim=1) for i in range(k)]
+
+
 class _GatherColumns(torch.autograd.Function):
     """gather_columns with autograd: the backward keeps this rank's own columns of the upstream gradient -- the
     parameters are sharded, not replicated, so there is NO gradient all-reduce."""
@@ -896,23 +917,29 @@ class _GatherColumns(torch.autograd.Function):
 
 
 def sharded_fused_train_one_step(Qb, qmb, teacher_shard: "TeacherScorer", student_shard: FusedStudent, temp: float,
-                                 shard_sizes, group=None, qidx: Optional[torch.Tensor] = None) -> float:
+                                 shard_sizes, group=None, qidx: Optional[torch.Tensor] = None, qplanes=None, sync: bool = True,
+                                 sc_t_local: Optional[torch.Tensor] = None):
     """`sharded_train_one_step` on the fused kernels: every rank scores its page shard for teacher and student, the two
-    (B, n_local) blocks are all-gathered, the loss kernel runs redundantly on the full rows, and each rank's slice of
-    d(loss)/d(scores) drives its own backward + AdamW kernel.  No autograd graph, no gradient all-reduce."""
+    (B, n_local) blocks ride in ONE all-gather (`gather_column_blocks`), the loss kernel runs redundantly on the full rows, and
+    each rank's slice of d(loss)/d(scores) drives its own backward + AdamW kernel.  No autograd graph, no gradient all-reduce.
+    `qplanes`: the batch's planes when they exist already (EpochBatches); `sc_t_local`: this rank's (B, n_local) teacher block when
+    it exists already (EpochBatches.teacher_scores over the shard's complete score cache); sync=False returns the loss as a device
+    scalar (the same number on every rank) instead of waiting for it."""
     import torch.distributed as dist
     device = student_shard.x.device
     Qb = Qb.to(device, non_blocking=True).float()
     qmb = qmb.to(device, non_blocking=True)
     rank = dist.get_rank(group)
     lo = int(sum(shard_sizes[:rank]))
-    qplanes = ops.split_f32(Qb)
+    if qplanes is None:
+        qplanes = ops.split_f32(Qb)
     sc_s_local, arg = student_shard.scores(Qb, qmb, qplanes)
-    sc_t = gather_columns(teacher_shard.scores(Qb, qmb, qidx, qplanes=qplanes), tuple(shard_sizes), group)
-    sc_s = gather_columns(sc_s_local, tuple(shard_sizes), group)
+    if sc_t_local is None:
+        sc_t_local = teacher_shard.scores(Qb, qmb, qidx, qplanes=qplanes)
+    sc_t, sc_s = gather_column_blocks([sc_t_local, sc_s_local], tuple(shard_sizes), group)
     loss, dscore = ops.infonce_distill(sc_s, sc_t, temp, want_grad=True, ws=student_shard.loss_workspace(sc_s.shape[0]))
     student_shard.apply(dscore[:, lo: lo + int(shard_sizes[rank])].contiguous(), Qb, qmb, arg)
-    return float(loss.item())
+    return float(loss.item()) if sync else loss
 
 
 def sharded_train_one_step(Qb, qmb, teacher_shard, Pbar_shard, pmask_student_shard, opt, temp: float,
