@@ -270,6 +270,14 @@ class CheckpointWriter:
                 self._cv.wait()
         self._check()
 
+    def backpressure(self, max_waiting: int) -> None:
+        """Wait until at most `max_waiting` snapshots are waiting (bounds the host memory they hold when files are produced
+        faster than one thread compresses them)."""
+        with self._cv:
+            while len(self._pending) > max_waiting:
+                self._cv.wait()
+        self._check()
+
     def close(self) -> None:
         if self._thread.is_alive():
             self.drain_quiet()
@@ -604,8 +612,8 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
                                               doc_attn_in=attn_in, doc_img_in=img_in, args=args, writer=writer)
             log_json(logger, summary_record(last, best_r1, best_nd5))
             if writer is not None:
-                writer.drain()                                      # "[done]" means: the files are there
-            if rank == 0:
+                writer.backpressure(8)                              # the last files of this run may still be in the writer's hands while
+            if rank == 0:                                           # the next (dataset, mf) trains; run() returns when all are on disk
                 print(f"[done] {dataset} mf{mf} -> {out_dir}")
             if tb is not None:
                 tb.flush()
