@@ -26,7 +26,7 @@ class _L2NormMasked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rowmask, eps):
         from .. import ops
-        if x.dim() == 3:
+        if x.dim() == 3 and x.numel() <= (1 << 30):                 # (up to 4 GiB of fp32: the planes take as much again while y lives)
             # page-shaped input (N, L, 128): the launch also leaves y as the scorer's fp16 hi/lo planes; _normalized() below
             # hangs them on the returned tensor, so that score_multi_vector_masked(Q, y, ...) -- the very next call in the
             # reference's step, mainv2_iter_distill_infonce.py:279,286 -- runs no absmax + split passes over y
