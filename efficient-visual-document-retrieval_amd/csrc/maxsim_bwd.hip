@@ -10,8 +10,11 @@
 namespace {
 
 constexpr int BW_THREADS = 512;
+#ifndef EVDR_BW_SMALL_WGS
+#define EVDR_BW_SMALL_WGS 384     /* launches of at most this many 128-row workgroups take 64-row slabs (A/B builds: -DEVDR_BW_FORCE_CAP=64|128) */
+#endif
 
-// One workgroup owns BW_ROWS consecutive patch rows of one page.  fp32 LDS atomics are NOT the accumulation path:
+// One workgroup owns up to BW_ROWS consecutive patch rows of one page (slab_rows of them: equally tall slabs per page).  fp32 LDS atomics are NOT the accumulation path:
 // ds_add_f32 costs ~175 cycles per wave-instruction on gfx950 (measured: 346 us with one atomic per pair, 28 us with plain
 // read-modify-write on this very kernel).  Instead the (query, token) pairs are bucketed by target row -- a STABLE counting
 // sort: per (row, wave-instruction) counts, exclusive scan, scatter by rank: three small LDS passes per chunk of pairs -- and
@@ -104,7 +107,7 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
                                                                const uint8_t* __restrict__ pmask,
                                                                const uint16_t* __restrict__ argmax,
                                                                float* __restrict__ dP, int nq, int lq, int np, int lp,
-                                                               AdamArgs ad) {
+                                                               int slab_rows, AdamArgs ad) {
     constexpr int PER_THREAD = CHUNK / BW_THREADS;
     constexpr int NGROUPS = BW_THREADS / 16;
     constexpr int NWAVES = BW_THREADS / 64;
@@ -119,8 +122,10 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
     uint32_t* cnt = reinterpret_cast<uint32_t*>(offs + BW_ROWS);         // [BW_ROWS][CW] pairs per (row, slot), one byte each
     __shared__ int sh_has, sh_total, sh_rounds;
     const int page = blockIdx.x;
-    const int r0 = blockIdx.y * BW_ROWS;
-    const int rows = min(BW_ROWS, lp - r0);
+    // BW_ROWS is the slab's CAPACITY (LDS); a workgroup owns slab_rows <= BW_ROWS rows, chosen per launch so that a page's slabs
+    // are equally tall (206 patches: 103 + 103, not 128 + 78)
+    const int r0 = blockIdx.y * slab_rows;
+    const int rows = min(slab_rows, lp - r0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = tid >> 6;
     const int gid = tid >> 4, sub = tid & 15;
@@ -671,9 +676,11 @@ static hipError_t launch_bwd(const float* g, const float* Q, const uint8_t* qmas
     auto kern = maxsim_bwd_kernel<BW_ROWS, CHUNK, FUSED>;
     static std::atomic<uint64_t> attr_devs{0};
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
-    dim3 grid((unsigned)np, (unsigned)((lp + BW_ROWS - 1) / BW_ROWS));
+    const int64_t nslabs = (lp + BW_ROWS - 1) / BW_ROWS;
+    const int slab_rows = (int)((lp + nslabs - 1) / nslabs);            // equally tall slabs, each within the capacity
+    dim3 grid((unsigned)np, (unsigned)nslabs);
     hipLaunchKernelGGL(kern, grid, dim3(BW_THREADS), LDS, stream, g, Q, qmask, pmask, argmax, dP, (int)nq, (int)lq, (int)np,
-                       (int)lp, ad);
+                       (int)lp, slab_rows, ad);
     return hipGetLastError();
 }
 
@@ -685,7 +692,17 @@ static hipError_t dispatch_bwd(const float* g, const float* Q, const uint8_t* qm
     // one 256-row slab: with one workgroup per CU the CU's HBM stream stops while that workgroup buckets and gathers, with
     // two the parameter / moment traffic of one overlaps the gather of the other -- 72 -> 62 us for the fused update at
     // B = 32, N = 500, Ls = 206 (316 MB of x / exp_avg / exp_avg_sq traffic: 5.1 TB/s), although every pair is bucketed twice
+    // Few workgroups (a page shard of a multi-GPU run: 63 pages x 2 slabs = 126 workgroups on 256 CUs): 64-row slabs (41 KiB of
+    // LDS: three workgroups per CU, twice the workgroups) -- 25.8 -> 17.7 us at 63 pages x 206 patches; with >= one workgroup
+    // per slot of the 128-row form the extra bucketing passes cost more than they hide (81.8 against 73.6 us at 500 pages).
+#if defined(EVDR_BW_FORCE_CAP) && EVDR_BW_FORCE_CAP == 64
+    return launch_bwd<64, 1024, FUSED>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, ad, stream);
+#elif defined(EVDR_BW_FORCE_CAP) && EVDR_BW_FORCE_CAP == 128
     return launch_bwd<128, 1024, FUSED>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, ad, stream);
+#else
+    if (lp > 64 && np * ((lp + 127) / 128) <= EVDR_BW_SMALL_WGS) return launch_bwd<64, 1024, FUSED>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, ad, stream);
+    return launch_bwd<128, 1024, FUSED>(g, Q, qmask, pmask, argmax, dP, nq, lq, np, lp, ad, stream);
+#endif
 }
 
 hipError_t evdr_launch_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,

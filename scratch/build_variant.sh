@@ -1,13 +1,19 @@
 #!/bin/bash
-# A variant of libevdr.so that differs from the product build by extra -D flags on maxsim_fwd16.hip only (the other objects are the
-# product build's): bash scratch/build_variant.sh <name> -DEVDR_REFILL_FRONT=1 ...   ->  scratch/ab/libevdr_<name>.so
+# A variant of libevdr.so that differs from the product build by extra -D flags on ONE source (the other objects are the product
+# build's): bash scratch/build_variant.sh <name> [--src maxsim_bwd] -DEVDR_REFILL_FRONT=1 ...   ->  scratch/ab/libevdr_<name>.so
 set -e
 name=$1; shift
+src=maxsim_fwd16
+if [ "$1" = "--src" ]; then src=$2; shift 2; fi
 R=$(cd "$(dirname "$0")/.." && pwd); P=$R/efficient-visual-document-retrieval_amd
 python3 -c "import sys; sys.path.insert(0, '$R'); import evdr_amd; from evdr_amd import build; build.build(verbose=False)"
 mkdir -p $R/scratch/ab /tmp/evdr_variant_$name
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -fno-honor-nans -std=c++17 -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form "$@" \
-    -c $P/csrc/maxsim_fwd16.hip -o /tmp/evdr_variant_$name/maxsim_fwd16.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/scratch/ab/libevdr_$name.so /tmp/evdr_variant_$name/maxsim_fwd16.o \
-    $P/build/maxsim_fwd.o $P/build/maxsim_bwd.o $P/build/topk.o $P/build/prep.o $P/build/evdr_capi.o
+extra=""; [ "$src" = "maxsim_fwd16" ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -fno-honor-nans -std=c++17 -Wall -Wno-unused-function $extra "$@" \
+    -c $P/csrc/$src.hip -o /tmp/evdr_variant_$name/$src.o
+objs=""
+for o in maxsim_fwd maxsim_fwd16 maxsim_bwd topk prep evdr_capi; do
+    if [ "$o" = "$src" ]; then objs="$objs /tmp/evdr_variant_$name/$o.o"; else objs="$objs $P/build/$o.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/scratch/ab/libevdr_$name.so $objs
 echo $R/scratch/ab/libevdr_$name.so
