@@ -79,6 +79,11 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
 #endif
     } else {
         qw = (p.nq > 8) ? 2 : 1;
+        // Small launches (a page shard of a multi-GPU training step: 32 queries x 63 pages = 126 workgroups of 16 queries on 256
+        // CUs): one query per wave makes twice the workgroups of half the matrix work each -- student forward + arg-max 20.9 ->
+        // 14.7 us, teacher forward 59.4 -> 40.8 us at 63 pages; from ~100 pages on (>= 200 workgroups) the two forms are level
+        // and two queries per wave move half the LDS bytes per FLOP.  Same bits.  Variant 36 keeps two per wave (A/B, tests).
+        if (qw == 2 && variant != 36 && (int64_t)((p.nq + 15) / 16) * p.np <= 128) qw = 1;
 #ifdef EVDR_EXPERIMENT
         if (variant == 13) qw = 2;          // dispatched as one query per wave on 4-wave workgroups (see maxsim_fwd16.hip)
         if (variant == 35) qw = 1;          // A/B: one query per wave (8 per workgroup, twice the query groups, half the prologue bytes per workgroup)

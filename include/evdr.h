@@ -267,7 +267,8 @@ int evdr_infonce_distill_fwd_bwd_ws(const float* score_s, const float* score_t, 
  * through a call.  evdr_debug_set_fwd_variant: force a forward-kernel family for the whole process (0 = default dispatch,
  * 1 = flat per-tile ring, 2 = staged kernel without the priority schedule, 10/11 = fp16-plane stage shapes (3 / 4 tiles),
  * 30 = one 8-wave workgroup per CU also for 3-12 queries, 31 = no non-temporal corpus stream, 33 / 34 = non-temporal stream of
- * the fp16-plane forward forced on / off (default: on for >= 128 MiB of planes read by <= 2 query groups); all variants compute the same
+ * the fp16-plane forward forced on / off (default: on for >= 128 MiB of planes read by <= 2 query groups), 36 = two queries per wave also
+ * for small fp16-plane launches (default: one per wave when 16-query workgroups would number <= 128); all variants compute the same
  * scores -- the test sweep runs each against the oracle); returns the previous value.
  * evdr_debug_set_pages_per_block: pages per workgroup (0 = automatic); returns the previous value.
  * evdr_last_fwd_kernel: host string naming the forward instance the last evdr_maxsim_fwd* / evdr_maxsim_topk call of

@@ -8,7 +8,7 @@ L.LIB_PATH = os.path.join(L.PKG_DIR, "libevdr_exp.so")
 from evdr_amd import ops
 dev = torch.device("cuda:0"); torch.manual_seed(0); lib = L.load()
 def unit(*s): return torch.nn.functional.normalize(torch.randn(*s, device=dev), dim=-1)
-for nq, np_, lp, am in [(32, 500, 206, True), (32, 500, 1030, False), (32, 125, 206, True)]:
+for nq, np_, lp, am in [(32, 500, 206, True), (32, 500, 1030, False), (32, 125, 206, True), (32, 63, 206, True), (32, 63, 1030, False), (32, 32, 1030, False), (32, 100, 206, True), (16, 63, 1030, False)]:
     Q, P = unit(nq, 32, 128), unit(np_, lp, 128)
     qp, qa = ops.split_f32(Q); pp, pa = ops.split_f32(P)
     tm, pf = ops.pack_pmask(None, np_, lp, dev)

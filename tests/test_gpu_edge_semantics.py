@@ -464,3 +464,33 @@ def test_pages_from_l2_normalize_bring_their_planes_to_the_scorer():
         assert torch.isnan(got[:, 2]).all() and not torch.isnan(got[:, 6]).any()
         ok = ~torch.isnan(want)
         np.testing.assert_allclose(got[ok].numpy(), want[ok].numpy(), atol=1e-4, rtol=0)
+
+
+def test_small_fp32_launches_take_one_query_per_wave_and_score_the_same_bits():
+    """A page shard of a multi-GPU training step (500 pages over 8 ranks = 63 pages x 32 queries) would be 126 workgroups of
+    16 queries on 256 CUs; the dispatch gives such launches one query per wave (twice the workgroups).  Same scores and arg-max, bit for
+    bit, as the two-per-wave form (variant 36) -- and both agree with the oracle; larger launches keep two per wave."""
+    import evdr_amd  # noqa: F401
+    import evdr_amd.ops as ops
+    from evdr_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(9)
+    unit = lambda *s: torch.nn.functional.normalize(torch.randn(*s, generator=g), dim=-1)
+    for nq, npg, lp, want_argmax, small in ((32, 63, 206, True, True), (32, 40, 300, False, True), (24, 63, 100, True, True), (32, 130, 206, True, False)):
+        Q, P = unit(nq, 32, 128), unit(npg, lp, 128)
+        qm = torch.rand(nq, 32, generator=g) > 0.1
+        pm = torch.rand(npg, lp, generator=g) > 0.1
+        got, arg = ops.maxsim_forward(Q.to(DEV), P.to(DEV), qm.to(DEV), pm.to(DEV), want_argmax=want_argmax)
+        name = lib.evdr_last_fwd_kernel().decode()
+        assert name.startswith("maxsim_fwd16s_kernel<1,2," if small else "maxsim_fwd16s_kernel<2,2,"), (nq, npg, name)
+        lib.evdr_debug_set_fwd_variant(36)
+        try:
+            two, arg2 = ops.maxsim_forward(Q.to(DEV), P.to(DEV), qm.to(DEV), pm.to(DEV), want_argmax=want_argmax)
+            assert lib.evdr_last_fwd_kernel().decode().startswith("maxsim_fwd16s_kernel<2,2,")
+        finally:
+            lib.evdr_debug_set_fwd_variant(0)
+        assert torch.equal(got, two) and (not want_argmax or torch.equal(arg, arg2))
+        want, warg = O.maxsim_masked_argmax(Q, P, qm, pm)
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4, rtol=0)
+        if want_argmax:
+            assert torch.equal(arg.cpu().to(torch.int32) & 0xFFFF, warg.to(torch.int32))

@@ -53,7 +53,7 @@ def test_random_forward_all_kernels(seed):
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4, rtol=0, err_msg=f"variant {variant}")
     got32, _ = ops.maxsim_forward(Q.float().to(dev), P.float().to(dev), *args)          # fp16 hi/lo path
     np.testing.assert_allclose(got32.cpu().numpy(), want.numpy(), atol=1e-4, rtol=0)
-    for variant in (33, 34):                          # the same with the non-temporal corpus stream forced on / off: same bits
+    for variant in (33, 34, 36):                      # the non-temporal corpus stream forced on / off, two queries per wave kept for small launches: same bits
         lib.evdr_debug_set_fwd_variant(variant)
         try:
             got, _ = ops.maxsim_forward(Q.float().to(dev), P.float().to(dev), *args)
