@@ -108,7 +108,12 @@ def test_committed_bench_line_follows_the_contract():
     assert sum(v["overlap_with_predecessor_avg_us"] for v in trace["kernels"].values()) < 1.0      # intervals of one queue do not overlap
     keys = ("maxsim_fwd16s_kernel<2, 2, false", "maxsim_fwd16s_kernel<2, 2, true", "maxsim_bwd_kernel")
     in_step = [r_["kernel_ms_in_step"] for r_ in t["roofline"]]
-    assert sum(in_step) < t["results"]["fused"]["ms_per_step"]
+    # the brackets (HIP events around each launch, the launch gap in front of it included) add up to less than the step they were taken in;
+    # that instrumented step is within 10 % of the plain one (since round 4's second session the step launches little else: the three
+    # kernels and the 7-us loss)
+    import re
+    with_events = float(re.search(r"step with the events ([0-9.]+) ms", t["roofline"][0]["kernel_ms_in_step_basis"]).group(1))
+    assert sum(in_step) < with_events < 1.10 * t["results"]["fused"]["ms_per_step"]
     prof_step = json.load(open(os.path.join(ROOT, "profiles", "r04_prof_train_line.json")))["results"]["fused"]["ms_per_step"]
     # per step: the step's own kernels (30 calls each in the 30 timed steps) plus the once-per-epoch preparation (driver.EpochBatches:
     # two gathers and one split launch per epoch, a few calls in the whole trace) spread over the steps
