@@ -188,8 +188,10 @@ def extras(dev, corpus_pages: torch.Tensor, args):
     import bench_train
     from evdr_amd import driver
     from evdr_amd.evaluator.retrieval import CustomRetrievalEvaluator
+    # cpu_pages = 500: the oracle step at the bench's OWN size (about 2.5 s of host work), so that its `cpu_baseline` also carries
+    # the step-level parity of configs[4] at N = 500 (loss / parameters / arg-max against the fused GPU step on the same inputs)
     train = bench_train.measure(pages=500, batch=32, steps=30, warmup=15, kinds=["call_pattern", "fused", "fused_cached"],
-                                cpu_pages=125, cpu_reps=1, dev=dev)
+                                cpu_pages=500, cpu_reps=1, dev=dev)
     n = min(500, corpus_pages.shape[0])
     pages = corpus_pages[:n]
     Qe, targets = make_queries(500, n, pages, 0, n, dev, 1)
@@ -289,6 +291,11 @@ def main():
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
         ok_mine, why = 1, None
         if backend == "nccl":
+            # a ONE-SIDED RCCL failure (group creation or the probe raising on one rank only) leaves the peers blocked in the probe's
+            # all-reduce until the data group's timeout; with torch's default async error handling the NCCL watchdog then ABORTS the
+            # process and the control-plane agreement below is never reached.  0 = the timeout surfaces as an exception on the
+            # waiting ranks instead.  (This path cannot be rehearsed on a 1-GPU pool: only the all-ranks-refuse case has been run.)
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
             try:
                 group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=240), device_id=dev)
                 probe = torch.ones(1, device=dev)
@@ -346,9 +353,12 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    corpus.score_events = []        # the dominant kernel of every TIMED step bracketed by HIP events on its launch stream
+    # the dominant kernel of every TIMED step bracketed by a HIP-event pair on its launch stream.  The timed step is the production
+    # path itself (ShardedRetriever.search -> PageCorpus.topk: evdr_maxsim_fwd_prepared + evdr_topk); the two event records are all
+    # that `score_events` adds to it
+    corpus.score_events = []
     for _ in range(min(2, args.warmup)):
-        step()                      # (warm the bracketed form of the step as well: the first event pair allocates)
+        step()                      # (the first event pair allocates)
     corpus.score_events.clear()
     fence()
     t0 = time.perf_counter()
@@ -529,6 +539,8 @@ def main():
                        "pages": args.pages, "patches_per_page": LP, "dim": D, "queries_per_step": args.queries,
                        "query_tokens": LQ, "topk": args.topk, "parallelism": f"page-shard x{world}"},
             "queries_per_sec": args.queries / (ms_per_step * 1e-3), "ndcg_at_5": ndcg5,
+            "timed_path": "ShardedRetriever.search -> PageCorpus.topk = evdr_maxsim_fwd_prepared + evdr_topk on the current stream "
+                          "(+ all-gather + merge at N > 1): the calls every search issues, plus one HIP-event pair around the MaxSim launch",
             "dist": {"world_size": dist.get_world_size() if multi else 1, "ranks_seen": ranks_seen,
                      "backend": dist.get_backend(group) if multi else None, "control_backend": "gloo" if multi else None,
                      "backend_requested": args.backend if multi else None,

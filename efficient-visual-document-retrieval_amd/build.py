@@ -18,7 +18,8 @@ OBJ_DIR = os.path.join(PKG_DIR, "build")
 SOURCES = ["maxsim_fwd.hip", "maxsim_fwd16.hip", "maxsim_bwd.hip", "topk.hip", "prep.hip", "evdr_capi.hip"]
 HEADERS = [os.path.join(CSRC, "evdr_common.h"), os.path.join(CSRC, "maxsim_device.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "evdr.h")]
 # -fno-honor-nans: lets fmaxf chains fold to v_max3_f32 without canonicalising moves (infinities are kept)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fno-honor-nans", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# -fvisibility=hidden: the dynamic symbol table holds the EVDR_API entry points of include/evdr.h and nothing else
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fno-honor-nans", "-fvisibility=hidden", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-source extras.  maxsim_fwd16.hip: MFMA destinations stay in VGPRs also in a kernel that uses AGPRs (the eight-queries-per-wave
 # instance keeps its query fragments there): LLVM otherwise switches such a kernel to the AGPR-destination form and reads every
 # accumulator back with v_accvgpr_read; every other instance compiles to the same instructions with or without the option
@@ -46,9 +47,10 @@ def build(force: bool = False, verbose: bool = True, experiment: bool = False, s
     loaded by the package).  sentinel=True builds libevdr_sentinel.so with -DEVDR_SENTINEL: the same kernels with every
     LDS-DMA piece poisoning its destination first (csrc/maxsim_device.h), loaded only by tests/test_gpu_sentinel.py.
     ring_fault (scratch/sentinel_control.py only): 1 removes the ring hand-over's vmcnt wait (a RAW race, libevdr[_sentinel]_fault.so),
-    2 issues the flat kernel's refill in front of the hand-over (a WAR race, libevdr[_sentinel]_faultwar.so)."""
+    2 issues the flat kernel's refill in front of the hand-over (a WAR race, libevdr[_sentinel]_faultwar.so), 3 does the same in the
+    STAGED two-slot ring -- the headline kernel's -- (libevdr[_sentinel]_faultwar2.so)."""
     suffix = "_exp" if experiment else ("_sentinel" if sentinel else "")
-    suffix += {0: "", 1: "_fault", 2: "_faultwar"}[int(ring_fault)]      # 1: hand-over without its vmcnt wait (RAW); 2: refill in front of it (WAR)
+    suffix += {0: "", 1: "_fault", 2: "_faultwar", 3: "_faultwar2"}[int(ring_fault)]   # 1: hand-over without its vmcnt wait (RAW); 2 / 3: refill in front of it (WAR: flat / staged ring)
     obj_dir = OBJ_DIR + suffix
     lib_path = LIB_PATH.replace("libevdr.so", f"libevdr{suffix}.so")
     flags = FLAGS + (["-DEVDR_EXPERIMENT"] if experiment else []) + (["-DEVDR_SENTINEL"] if sentinel else []) + (
@@ -88,4 +90,4 @@ def build(force: bool = False, verbose: bool = True, experiment: bool = False, s
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, experiment="--experiment" in sys.argv, sentinel="--sentinel" in sys.argv,
-          ring_fault=2 if "--ring-fault-war" in sys.argv else int("--ring-fault" in sys.argv))
+          ring_fault=3 if "--ring-fault-war2" in sys.argv else (2 if "--ring-fault-war" in sys.argv else int("--ring-fault" in sys.argv)))

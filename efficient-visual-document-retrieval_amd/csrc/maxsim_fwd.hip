@@ -18,14 +18,15 @@
 
 #include "maxsim_device.h"
 
-// Test / experiment hooks (include/evdr.h "debug hooks"): process-wide, set explicitly through the C ABI.  The library
-// reads no environment variable.
-static std::atomic<int> g_fwd_variant{0};
-static std::atomic<int> g_pages_per_block{0};
+// Test / experiment hooks (include/evdr.h "debug hooks"): THREAD-LOCAL, set explicitly through the C ABI -- an override applies
+// to the launches the calling thread issues afterwards and to nothing else, so the library holds no shared mutable state that
+// concurrent callers could race on.  The library reads no environment variable.
+static thread_local int g_fwd_variant = 0;
+static thread_local int g_pages_per_block = 0;
 static thread_local const char* g_last_fwd_kernel = "";
-int evdr_fwd_variant_exchange(int v) { return g_fwd_variant.exchange(v); }
-int evdr_pages_per_block_exchange(int v) { return g_pages_per_block.exchange(v); }
-int evdr_pages_per_block_override() { return g_pages_per_block.load(std::memory_order_relaxed); }
+int evdr_fwd_variant_exchange(int v) { const int old = g_fwd_variant; g_fwd_variant = v; return old; }
+int evdr_pages_per_block_exchange(int v) { const int old = g_pages_per_block; g_pages_per_block = v; return old; }
+int evdr_pages_per_block_override() { return g_pages_per_block; }
 void evdr_note_fwd_kernel(const char* name) { g_last_fwd_kernel = name; }
 const char* evdr_last_fwd_kernel_name() { return g_last_fwd_kernel; }
 
@@ -34,7 +35,7 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
     // groups of 17-20 at three per wave with a sixth of the wave slots empty: 9.0 instead of 9.6 ms for 40 queries x 40 k pages
     // (the remainder's pass over the corpus costs less than the idle slots; from 41 queries on the balanced groups win).
     if (nplanes == 1 && !want_argmax && pin.nq > 32 && pin.nq <= 40 && !pin.per_token && pin.qlist == nullptr &&
-        g_fwd_variant.load(std::memory_order_relaxed) == 0) {
+        g_fwd_variant == 0) {
         EvdrFwdParams a = pin, b = pin;
         a.nq = 32;
         b.nq = pin.nq - 32;
@@ -48,7 +49,7 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
     p.ntiles = (p.lp + EVDR_TILE_PATCHES - 1) / EVDR_TILE_PATCHES;
     // more queries per wave = more MFMAs per LDS read, bounded by the 256 VGPRs of a wave at 2 waves per SIMD:
     // 32 per bf16 query, 64 per fp16 hi/lo query, a few more for the running argmax
-    const int variant = g_fwd_variant.load(std::memory_order_relaxed);   // 0 = default dispatch (evdr_debug_set_fwd_variant)
+    const int variant = g_fwd_variant;   // 0 = default dispatch (evdr_debug_set_fwd_variant)
     int qw, waves = 8;
     if (nplanes == 1 && !want_argmax) {
         // Queries per wave from the batch size: a workgroup covers 8 * qw queries, and a workgroup with idle waves takes as

@@ -794,7 +794,11 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             // (In-block, the whole next stage is fetched, also tiles outside the page's valid range.)
             const bool next_rows = (nk + 1) * ST * EVDR_TILE_PATCHES <= p.lp;     // every row of the next stage exists
             const bool next_full = refill && next_rows;
+#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT == 3
+            const bool spread = false;                                     // (control build: the whole refill goes out in front of the hand-over, below)
+#else
             const bool spread = fast && next_full && spread_ok;
+#endif
             // one base pointer for the whole next stage (two SGPRs), the tile window of its page, and which of this wave's G
             // pieces lie inside it
             const uint16_t* nbase = fbase;
@@ -813,12 +817,34 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             if constexpr (DIAG) { d_a = stamp(); d_ctl += d_a - d_c0; }
             // stage hand-over (ring_barrier, maxsim_device.h): this wave's pieces of the stage have landed and every ds_read it
             // has issued is retired BEFORE it arrives; nothing can be scheduled into or across the statement
+#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT == 3
+            // WAR control of the sentinel instrument for THIS (staged, two-slot) ring -- never a shipped build (build.py ring_fault=3,
+            // scratch/sentinel_control.py): the refill of slot `nslot` is issued IN FRONT of the hand-over that retires the
+            // ds_reads of the stage the slower waves of the workgroup may still be computing from that very slot.  This wave's own
+            // reads of the slot are retired first (lgkmcnt(0)), so what is left is exactly the cross-wave write-after-read edge the
+            // hand-over exists for.  (RAW stays intact: the hand-over's vmcnt(0) below also covers the pieces issued here.)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (refill) {
+                if (next_rows) {
+#pragma unroll
+                    for (int i = 0; i < G; ++i)
+                        if ((want >> i) & 1u) issue_piece(nbase, nt0, 0, 0, nslot, i, std::true_type{});
+                    issue_extra(npgi, nk, nthi, nslot);
+                } else {
+                    issue_stage(npgi, nk, ntlo, nthi, nslot);
+                }
+            }
+#endif
             ring_barrier<0>();
             // the flag word of the page after the fetch cursor's: a scalar load with a whole stage to land in (the next hand-over
             // retires it; the value is first used when the fetch cursor opens that page)
             if (load_apf) apf = pageflags_c[pg0 + npgi + 1];
             if constexpr (DIAG) { const unsigned long long t = stamp(); d_bar += t - d_a; d_a = t; }
+#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT == 3
+            if (false) {
+#else
             if (refill && !spread) {
+#endif
                 if (next_rows) {                                        // no row of the stage needs clamping: constant offsets
                     if (want == (1u << G) - 1u) {
 #pragma unroll
@@ -1219,7 +1245,7 @@ hipError_t launch16(const EvdrFwdParams& pin, hipStream_t stream) {
 #ifdef EVDR_EXPERIMENT
 static unsigned long long* g_dbg_buffer = nullptr;
 unsigned long long* evdr_experiment_dbg_buffer() { return g_dbg_buffer; }
-extern "C" void evdr_experiment_set_dbg_buffer(void* dev_ptr) { g_dbg_buffer = (unsigned long long*)dev_ptr; }
+extern "C" EVDR_API void evdr_experiment_set_dbg_buffer(void* dev_ptr) { g_dbg_buffer = (unsigned long long*)dev_ptr; }
 #endif
 
 hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, int nplanes, bool want_argmax, int geom, hipStream_t stream) {

@@ -314,6 +314,7 @@ def save_best_npz(*, out_dir: Path, fname: str, dataset: str, mf: int, step: int
     if writer is None:
         job()
     else:
+        print(f"[save] queued {target} (step {int(step)})")      # "[save] <path>" follows when the file is on disk
         writer.submit(target, job)
 
 
@@ -358,12 +359,49 @@ def build_argparser():
     p.add_argument("--sync_checkpoints", action="store_true",
                    help="write best_*.npz inline like the reference (default: one background thread compresses and writes them; "
                         "the files are the same)")
-    p.add_argument("--fused_step", action="store_true",
+    # The two result-identical fast paths are the DEFAULT: `python -m evdr_amd.driver` with the reference's flags alone runs the
+    # fused 0.15-ms step (the teacher is frozen, caching its scores is "a legal, result-identical optimisation";
+    # tests/test_gpu_driver.py pins both forms to the reference's own train_one_step).  --no_* restores the reference's call pattern.
+    p.add_argument("--fused_step", dest="fused_step", action="store_true", default=None,
                    help="student update through evdr_maxsim_bwd_adamw (backward + normalise backward + AdamW in one kernel; "
-                        "result-identical to autograd + torch.optim.AdamW)")
-    p.add_argument("--cache_teacher_scores", action="store_true",
-                   help="keep the (n_train_queries, N) teacher score matrix on the device (result-identical)")
+                        "result-identical to autograd + torch.optim.AdamW).  Default: on when --opt is adamw")
+    p.add_argument("--no_fused_step", dest="fused_step", action="store_false",
+                   help="the reference's step: autograd through the drop-in scorer + the optimizer of --opt")
+    p.add_argument("--cache_teacher_scores", dest="cache_teacher_scores", action="store_true", default=None,
+                   help="keep the (n_train_queries, N) teacher score matrix on the device (result-identical: the teacher is frozen). "
+                        "Default: on while it fits --teacher_cache_gb")
+    p.add_argument("--no_cache_teacher_scores", dest="cache_teacher_scores", action="store_false",
+                   help="recompute the teacher's scores every step like the reference (mainv2_iter_distill_infonce.py:282-283)")
+    p.add_argument("--teacher_cache_gb", type=float, default=8.0,
+                   help="byte budget of the teacher score cache per dataset (n_train_queries x pages-on-this-rank x 4 B); a cache that "
+                        "does not fit is not made, which is logged, and the teacher is scored per step")
     return p
+
+
+def resolve_fast_paths(args, n_train: int, n_pages_local: int, log=print) -> Tuple[bool, bool]:
+    """(fused step?, teacher score cache?) for one dataset from the flags -- None = not given = the default: both on.  The fused
+    kernel implements AdamW only: with another --opt the default falls back to the autograd step (an EXPLICIT --fused_step is an
+    error there).  The cache is bounded by --teacher_cache_gb; a fallback is logged, never silent."""
+    fused = getattr(args, "fused_step", None)
+    if fused is None:
+        fused = args.opt == "adamw"
+        if not fused:
+            log(f"[fast paths] --opt {args.opt}: the fused step implements AdamW only -> autograd step + torch optimizer")
+    elif fused and args.opt != "adamw":
+        raise ValueError("--fused_step implements AdamW only")
+    cache = getattr(args, "cache_teacher_scores", None)
+    explicit = cache is not None
+    if cache is None:
+        cache = True
+    if cache:
+        need = int(n_train) * int(n_pages_local) * 4
+        budget = float(getattr(args, "teacher_cache_gb", 8.0)) * (1 << 30)
+        if need > budget:
+            log(f"[fast paths] teacher score cache {'(asked for) ' if explicit else ''}needs {need / (1 << 30):.2f} GiB "
+                f"({n_train} queries x {n_pages_local} pages x 4 B) > --teacher_cache_gb {budget / (1 << 30):.2f}: not made, "
+                f"the teacher is scored every step")
+            cache = False
+    return bool(fused), bool(cache)
 
 
 def _dist_context():
@@ -406,7 +444,14 @@ def run(args) -> None:
     writer = None if getattr(args, "sync_checkpoints", False) else CheckpointWriter()
     try:
         _run(args, writer)
-    finally:
+    except BaseException:
+        if writer is not None:                        # the run's own exception stays the primary error: the writer's, if any, is logged
+            try:
+                writer.close()
+            except Exception as e:                    # noqa: BLE001
+                print(f"[save] while handling the run's error: {e}")
+        raise
+    else:
         if writer is not None:
             writer.close()
 
@@ -434,6 +479,13 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
         return qp, tp, inits, host_pages
 
     loader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="evdr-dataset-loader")
+    try:
+        _run_datasets(args, writer, loader, read_dataset, mapping, device, rank, world)
+    finally:
+        loader.shutdown(wait=False, cancel_futures=True)       # also on an exception: no read-ahead left running behind it
+
+
+def _run_datasets(args, writer, loader, read_dataset, mapping, device, rank, world) -> None:
     ahead = {}
     for di, dataset in enumerate(args.datasets):
         paths = mapping[dataset]
@@ -461,7 +513,12 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
                  "teacher_rows_on_device": int(P_t_raw.shape[0]),
                  "peak_bytes_after_teacher_load": int(torch.cuda.max_memory_allocated(device))}
         LOAD_STATS.append(stats)
-        teacher = TeacherScorer(P_t_norm, pmask_t, cache_size=n_train if args.cache_teacher_scores else 0)
+        use_fused, use_cache = resolve_fast_paths(args, n_train, int(P_t_norm.shape[0]), log=(print if rank == 0 else (lambda *_: None)))
+        stats["fused_step"], stats["teacher_score_cache"] = use_fused, use_cache
+        if rank == 0:
+            print(f"[fast paths] {dataset}: fused step {'on' if use_fused else 'off'}, teacher score cache {'on' if use_cache else 'off'}"
+                  + (f" ({n_train * int(P_t_norm.shape[0]) * 4 / (1 << 20):.1f} MiB)" if use_cache else ""))
+        teacher = TeacherScorer(P_t_norm, pmask_t, cache_size=n_train if use_cache else 0)
         test_teacher_scores: Dict[str, Any] = {}              # the teacher's scores of the test queries: constant over the run
         del P_t_raw
         steps_per_epoch = (n_train + args.q_batch - 1) // args.q_batch
@@ -482,9 +539,7 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
                 raise ValueError(f"init doc count mismatch: got {len(Pbar_obj)} vs teacher {n_pages}")
             Pbar_raw, pmask_s = _shard_docs(Pbar_obj, attn_in, img_in, lo, hi, world, device)
             stats[f"student_rows_on_device_mf{mf}"] = int(Pbar_raw.shape[0])
-            if args.fused_step:
-                if args.opt != "adamw":
-                    raise ValueError("--fused_step implements AdamW only")
+            if use_fused:
                 student = FusedStudent(Pbar_raw, pmask_s, lr=args.lr, weight_decay=args.weight_decay)
                 Pbar_param, opt = student.x, None                 # evaluated / checkpointed through the same tensor
             else:
@@ -554,7 +609,7 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
                     if use_epoch:
                         epoch = EpochBatches(Q_train, qmask_train, perm_dev, args.q_batch, planes=student is not None, teacher=teacher)
                 idx = perm[cursor:cursor + args.q_batch]
-                qidx = idx if args.cache_teacher_scores else None
+                qidx = idx if use_cache else None
                 if perm_dev is not None:
                     idx = perm_dev[cursor:cursor + args.q_batch]
                 qpl_step = sct_step = None
@@ -618,7 +673,6 @@ def _run(args, writer: Optional[CheckpointWriter]) -> None:
             if tb is not None:
                 tb.flush()
                 tb.close()
-    loader.shutdown(wait=True)
 
 
 class EpochBatches:

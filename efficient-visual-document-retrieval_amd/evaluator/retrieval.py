@@ -52,10 +52,7 @@ def forget_prepared() -> None:
     ops._DERIVED.clear()
 
 
-def _tensor_key(t: Optional[torch.Tensor]):
-    if t is None:
-        return None
-    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t.device.index, t._version)
+_tensor_key = ops.tensor_key           # None for None AND for inference tensors (no version counter: never cached)
 
 
 def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
@@ -64,7 +61,8 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
     a miss only -- keyed on a padded temporary, every call would redo pad + split + mask packing + the non-finite scan and push a
     live entry out of the small LRU."""
     key = (_tensor_key(P), _tensor_key(pmask))
-    hit = _PREPARED.get(key)
+    cacheable = key[0] is not None and (pmask is None or key[1] is not None)       # not under torch.inference_mode()
+    hit = _PREPARED.get(key) if cacheable else None
     if hit is not None and hit[0]() is not None and (pmask is None or hit[1]() is not None):
         _PREPARED.move_to_end(key)
         return hit[2]
@@ -79,7 +77,7 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
     ops.flag_nonfinite(planes[0], pmask, pageflags)
     prep = (planes, amax, tilemask, pageflags)
     nbytes = 0 if (Pw is P and P.dtype == torch.bfloat16 and P.is_contiguous()) else planes.numel() * planes.element_size()
-    if nbytes <= _PREPARED_MAX_BYTES:
+    if cacheable and nbytes <= _PREPARED_MAX_BYTES:
         drop = lambda _ref, key=key: _PREPARED.pop(key, None)          # the tensor died: free its planes right away
         _PREPARED[key] = (weakref.ref(P, drop), weakref.ref(pmask, drop) if pmask is not None else None, prep, nbytes)
         while len(_PREPARED) > _PREPARED_MAX or sum(e[3] for e in _PREPARED.values()) > _PREPARED_MAX_BYTES:
@@ -95,6 +93,8 @@ def _query_planes(Q: torch.Tensor):
     and against the student (mainv2_iter_distill_infonce.py:283,286) -- so the last batch's planes are kept while that tensor is
     alive and unwritten (key as for the prepared pages)."""
     key = _tensor_key(Q)
+    if key is None:                                     # inference tensor: split per call
+        return ops.split_f32(Q)
     if _QPLANES and _QPLANES[0][1] == key and _QPLANES[0][0]() is not None:
         return _QPLANES[0][2]
     made = ops.split_f32(Q)

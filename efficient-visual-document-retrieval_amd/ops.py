@@ -390,12 +390,20 @@ _DERIVED: "collections.OrderedDict" = collections.OrderedDict()
 _DERIVED_MAX = 8
 
 
-def tensor_key(t: torch.Tensor):
+def tensor_key(t: Optional[torch.Tensor]):
+    """Identity of a tensor's CONTENT for the per-tensor caches (derived planes here, prepared pages and query planes in
+    evaluator/retrieval.py): storage address, layout and autograd version counter -- any in-place torch write changes it.
+    None = not cacheable: tensors made under torch.inference_mode() track no version counter (`t._version` raises for them), so
+    nothing is ever remembered for or looked up by such a tensor; the scorer then prepares its operands per call."""
+    if t is None or t.is_inference():
+        return None
     return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t.device.index, t._version)
 
 
 def remember_planes(y: torch.Tensor, planes: torch.Tensor, amax: torch.Tensor) -> None:
     key = tensor_key(y)
+    if key is None:
+        return
     _DERIVED[key] = (weakref.ref(y, lambda _r, key=key: _DERIVED.pop(key, None)), planes, amax)
     while len(_DERIVED) > _DERIVED_MAX:
         _DERIVED.popitem(last=False)
@@ -404,7 +412,8 @@ def remember_planes(y: torch.Tensor, planes: torch.Tensor, amax: torch.Tensor) -
 def planes_of(t: torch.Tensor):
     """(planes, absmax word) made together with `t` (same storage, layout and autograd version: any in-place torch write
     since then changes the key), or None."""
-    hit = _DERIVED.get(tensor_key(t))
+    key = tensor_key(t)
+    hit = _DERIVED.get(key) if key is not None else None
     if hit is None or hit[0]() is None:
         return None
     return hit[1], hit[2]

@@ -26,10 +26,15 @@ class _L2NormMasked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rowmask, eps):
         from .. import ops
-        if x.dim() == 3 and x.numel() <= (1 << 30):                 # (up to 4 GiB of fp32: the planes take as much again while y lives)
-            # page-shaped input (N, L, 128): the launch also leaves y as the scorer's fp16 hi/lo planes; _normalized() below
-            # hangs them on the returned tensor, so that score_multi_vector_masked(Q, y, ...) -- the very next call in the
-            # reference's step, mainv2_iter_distill_infonce.py:279,286 -- runs no absmax + split passes over y
+        if (x.dim() == 3 and x.numel() <= (1 << 30) and ctx.needs_input_grad[0] and torch.is_grad_enabled()
+                and not torch.is_inference_mode_enabled()):
+            # page-shaped TRAINABLE input (N, L, 128) -- the reference's Psb = l2_normalize(Pbar_param * pmask), scored by the very
+            # next call of its step (mainv2_iter_distill_infonce.py:279,286): the launch also leaves y as the scorer's fp16 hi/lo
+            # planes and _normalized() below hangs them on the returned tensor, so that score_multi_vector_masked(Q, y, ...) runs no
+            # absmax + split passes over y.  Only there: a tensor normalised without a graph (the teacher at load time,
+            # preprocess_queries, evaluation under no_grad) may never be scored, and its planes would hold a second copy of it in
+            # HBM for as long as it lives (up to 4 GiB); such pages are split by the scorer when -- and if -- they are scored, and
+            # frozen ones are cached there (evaluator/retrieval._prepared_pages).
             y, norm, planes, amax = ops.l2norm_forward(x, rowmask, eps, want_planes=True)
             _L2NormMasked.last_planes = (y.data_ptr(), planes, amax)
         else:

@@ -18,8 +18,8 @@
  *     reference itself drives its scorer from a single Python thread, DataLoader(num_workers=0);
  *     mainv2_iter_distill_infonce.py:269-321).  The library keeps no mutable state between calls except (a) per kernel
  *     instance, the set of devices on which its dynamic-LDS limit has been raised -- an atomic bit set, and raising the limit
- *     twice is harmless -- and (b) the process-wide debug hooks below (atomics: a test tool, not for concurrent use).
- *     evdr_last_error() and evdr_last_fwd_kernel() are thread-local: a thread reads its own.  Ordering between calls that
+ *     twice is harmless.  evdr_last_error(), evdr_last_fwd_kernel() and the two debug overrides at the end of this file are
+ *     THREAD-LOCAL: a thread reads and sets its own, no caller can change what another caller's launch does.  Ordering between calls that
  *     touch the same buffers is the caller's (streams / events), as with any HIP launch; workspaces are per call.
  *     tests/cabi/cabi_threads.cpp: eight threads, one kernel family each, first launches racing, bit-equal to serial calls.
  *     Several processes per node (one per GPU: corpus.py / bench.py) are the multi-GPU form;
@@ -54,6 +54,10 @@
 extern "C" {
 #endif
 
+/* The entry points below are the library's ONLY dynamic symbols: libevdr.so is built with -fvisibility=hidden and each of them
+ * carries default visibility (tests/test_cabi_exports.py compares `nm -D --defined-only` with this header, both ways). */
+#define EVDR_API __attribute__((visibility("default")))
+
 #define EVDR_OK            0
 #define EVDR_ERR_ARG       1   /* null pointer / bad enum / negative size            */
 #define EVDR_ERR_SHAPE     2   /* unsupported shape (D != 128, Lp > 65535 w/ argmax) */
@@ -66,8 +70,8 @@ extern "C" {
 
 #define EVDR_TOPK_MAX 128      /* k_values max is 100 (evaluator/retrieval.py:223)   */
 
-int         evdr_version(void);          /* 10000*major + 100*minor + patch */
-const char* evdr_last_error(void);       /* host string, thread-local, valid until the next call */
+EVDR_API int         evdr_version(void);          /* 10000*major + 100*minor + patch */
+EVDR_API const char* evdr_last_error(void);       /* host string, thread-local, valid until the next call */
 
 /* ---- corpus preparation (the steps either side of the hot loop; cacheable for a static corpus) ---- */
 
@@ -81,7 +85,7 @@ const char* evdr_last_error(void);       /* host string, thread-local, valid unt
  *          vb = bits 16..31, and the kernels walk / fetch only that range; otherwise (holes) bits 16..31 = index of the
  *          first masked patch and the tile words decide
  *   bit3 = a valid patch holds a NaN / Inf element (set by evdr_flag_nonfinite, never here). */
-int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp,
+EVDR_API int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp,
                     uint32_t* tilemask, uint32_t* pageflags, void* hip_stream);
 
 /* Split `rows` x 128 fp32 into two fp16 planes hi/lo of x * 2^k, hi + lo == x * 2^k to 2^-22 relative.  k is one
@@ -89,7 +93,7 @@ int evdr_pack_pmask(const uint8_t* pmask, int64_t np, int64_t lp,
  * the lo plane of every element that matters is a normal number).  planes: 2 * rows * 128 uint16 (fp16 bits),
  * plane-major.  amax_bits: 1 uint32 on the device = bits of max|x| (the kernels derive k from it; keep it with the
  * planes).  Three fp16 MFMA products lo*hi + hi*lo + hi*hi then give the fp32 dot product to below fp32 rounding noise. */
-int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, void* hip_stream);
+EVDR_API int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* amax_bits, void* hip_stream);
 
 /* evdr_split_f32 of MANY small tensors laid end to end, in one launch: segment s = rows [s * seg_rows, (s + 1) * seg_rows) of
  * x (the last segment may be short; seg_rows <= 2048, at most 65535 segments) -- the batches of a training epoch, whose
@@ -98,13 +102,13 @@ int evdr_split_f32(const float* x, int64_t rows, uint16_t* planes, uint32_t* ama
  * are bit for bit those of evdr_split_f32 applied to that segment alone.  Segment s's planes are the contiguous
  * (2, rows_s, 128) block at planes + s * 2 * seg_rows * 128 -- what evdr_maxsim_fwd_prepared takes as Q planes.
  * planes: 2 * rows * 128 uint16 (rounded up to whole segments: ceil(rows / seg_rows) * 2 * seg_rows * 128). */
-int evdr_split_f32_segments(const float* x, int64_t rows, int64_t seg_rows, uint16_t* planes, uint32_t* amax_bits, void* hip_stream);
+EVDR_API int evdr_split_f32_segments(const float* x, int64_t rows, int64_t seg_rows, uint16_t* planes, uint32_t* amax_bits, void* hip_stream);
 
 /* Report non-finite page content: sets bit 3 of pageflags[p] (made by evdr_pack_pmask) when a valid patch of page p holds a
  * NaN or +-Inf element; the forward kernels then return NaN for that page ("Non-finite inputs" above).  P: (np, lp, 128)
  * of dtype EVDR_F32, EVDR_BF16 or EVDR_F16 (the hi plane of fp16 hi/lo planes), `p_stride` elements between pages.  One
  * read of P; flags are only ever set, re-run evdr_pack_pmask to clear them. */
-int evdr_flag_nonfinite(const void* P, int dtype, const uint8_t* pmask, int64_t np, int64_t lp, int64_t p_stride,
+EVDR_API int evdr_flag_nonfinite(const void* P, int dtype, const uint8_t* pmask, int64_t np, int64_t lp, int64_t p_stride,
                         uint32_t* pageflags, void* hip_stream);
 
 /* ---- A1: score_multi_vector_masked (evaluator/retrieval.py:166-213) ---------------------------------
@@ -121,8 +125,8 @@ int evdr_flag_nonfinite(const void* P, int dtype, const uint8_t* pmask, int64_t 
  * all of P: with 1-8 queries per call, where the scorer itself only streams P once, that roughly doubles the call) and,
  * for EVDR_F32, splits P into fp16 planes.  A caller that scores the same pages more than once should prepare them once
  * (evdr_pack_pmask + evdr_flag_nonfinite [+ evdr_split_f32]) and call evdr_maxsim_fwd_prepared. */
-size_t evdr_maxsim_fwd_workspace(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype);
-int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const uint8_t* pmask,
+EVDR_API size_t evdr_maxsim_fwd_workspace(int64_t nq, int64_t lq, int64_t np, int64_t lp, int dtype);
+EVDR_API int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const uint8_t* pmask,
                     float* out, uint16_t* argmax_or_null,
                     int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d, int dtype,
                     const int64_t* strides_or_null,
@@ -136,7 +140,7 @@ int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const ui
  * shard can write its column block of a wider (nq, N) matrix.  This is the bench / retrieval
  * hot path (SURVEY §8(d),(e)).  qlist_ws_or_null: (nq + 1) int32 of scratch, used when lq > 32 to score the later
  * 32-token slices only for the queries that have valid tokens there (query sets are padded to their longest member). */
-int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes,
+EVDR_API int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes,
                              const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
                              float* out, int64_t out_stride, uint16_t* argmax_or_null,
                              int64_t nq, int64_t lq, int64_t np, int64_t lp,
@@ -148,7 +152,7 @@ int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes,
  * dP[p,m,:] = sum_{q,n} g[q,p] * qmask[q,n] * has(p) * [m == argmax[q,p,n]] * Q[q,n,:]
  * g (nq,np) fp32; Q (nq,lq,128) fp32; argmax from evdr_maxsim_fwd; dP (np,lp,128) fp32 is
  * OVERWRITTEN (every element written, masked rows get exact zeros). */
-int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
+EVDR_API int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                     const uint16_t* argmax, float* dP,
                     int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d, void* hip_stream);
 
@@ -157,8 +161,8 @@ int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const 
  * g (nq,np) fp32; P (np,lp,128) fp32 dense; argmax from evdr_maxsim_fwd; dQ (nq,lq,128) fp32 is OVERWRITTEN.
  * Deterministic: with few (query, token) pairs the page range is split over workgroups, whose partial sums go to the
  * workspace and are added in a fixed order (no float atomics) -- the same bits run after run. */
-size_t evdr_maxsim_bwd_q_workspace(int64_t nq, int64_t lq, int64_t np, int64_t lp);
-int evdr_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint8_t* pmask,
+EVDR_API size_t evdr_maxsim_bwd_q_workspace(int64_t nq, int64_t lq, int64_t np, int64_t lp);
+EVDR_API int evdr_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, const uint8_t* pmask,
                       const uint16_t* argmax, float* dQ,
                       int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d,
                       void* workspace, size_t workspace_bytes, void* hip_stream);
@@ -172,7 +176,7 @@ int evdr_maxsim_bwd_q(const float* g, const float* P, const uint8_t* qmask, cons
  * lr / betas / eps / weight_decay are DOUBLES, as Python hands them to torch: the derived constants (1 - lr * weight_decay,
  * 1 - beta, lr / (1 - beta1^step), ...) are formed in double on the host like torch forms them and only then rounded to fp32
  * (1 - float(0.999) would be off by 1.3e-5 relative). */
-int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
+EVDR_API int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                           const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq,
                           int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d,
                           double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
@@ -182,7 +186,7 @@ int evdr_maxsim_bwd_adamw(const float* g, const float* Q, const uint8_t* qmask, 
  * word; both or neither), non-finite updated rows reported in pageflags_or_null (np words, bit 3) like there.  A training
  * loop that keeps the planes (mainv2_iter_distill_infonce.py:279 normalises the parameter at the top of EVERY step) saves
  * the separate normalise pass: one read of x and one launch per step. */
-int evdr_maxsim_bwd_adamw_planes(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
+EVDR_API int evdr_maxsim_bwd_adamw_planes(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask,
                                  const uint16_t* argmax, float* x, float* exp_avg, float* exp_avg_sq,
                                  int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d,
                                  double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
@@ -193,12 +197,12 @@ int evdr_maxsim_bwd_adamw_planes(const float* g, const float* Q, const uint8_t* 
  * replayed without a scalar from the host: adamw_state = 16 bytes of device memory {int64 step; float bc1; float bc2_sqrt},
  * zero-initialised.  evdr_adamw_advance does step += 1 and refreshes the bias corrections; evdr_maxsim_bwd_adamw with a
  * non-NULL state reads them from there and ignores its `step` argument. */
-int evdr_adamw_advance(void* adamw_state, double beta1, double beta2, void* hip_stream);
+EVDR_API int evdr_adamw_advance(void* adamw_state, double beta1, double beta2, void* hip_stream);
 /* The optimizer of A7 on its own (utils/utils.py:78-80 -> torch.optim.AdamW at torch's default betas / eps, amsgrad off), for
  * callers that keep the reference's autograd step (loss.backward(); opt.step(), mainv2_iter_distill_infonce.py:290-291): one
  * pass over grad, x, exp_avg, exp_avg_sq (n fp32 elements each, 16-byte aligned, dense), in place; `step` >= 1 is the count
  * INCLUDING this update (bias corrections 1 - beta^step).  torch's default (foreach) form makes eight passes. */
-int evdr_adamw_step(const float* grad, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+EVDR_API int evdr_adamw_step(const float* grad, float* x, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
                     double beta2, double eps, double weight_decay, int64_t step, void* hip_stream);
 
 /* ---- A4: l2_normalize (utils/preprocess_data.py:8-9) fused with the page mask, forward and backward -----------------
@@ -207,16 +211,16 @@ int evdr_adamw_step(const float* grad, float* x, float* exp_avg, float* exp_avg_
  * the four ATen kernels of l2_normalize on the training step (mainv2_iter_distill_infonce.py:279).
  * Backward: dx = m * ( gy/(n+eps) - (m x) * ((m x).gy) / (n (n+eps)^2) ), with the norm's subgradient 0 at n = 0
  * (what torch autograd yields for x / (x.norm() + eps)). */
-int evdr_l2norm_fwd(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps,
+EVDR_API int evdr_l2norm_fwd(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps,
                     float* y, float* norm_or_null, void* hip_stream);
-int evdr_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask_or_null, const float* norm,
+EVDR_API int evdr_l2norm_bwd(const float* gy, const float* x, const uint8_t* rowmask_or_null, const float* norm,
                     int64_t rows, int64_t d, float eps, float* dx, void* hip_stream);
 /* evdr_l2norm_fwd that also (or only: y_or_null = NULL) emits y in evdr_split_f32's format -- fp16 hi/lo planes
  * (2 * rows * 128 uint16) + the absmax word, here the constant bits of 1.0f since |y| <= 1 -- ready for
  * evdr_maxsim_fwd_prepared(nplanes = 2): the normalised student pages of a training step go to the scorer without an
  * fp32 round trip through HBM (mainv2_iter_distill_infonce.py:279-283).  pageflags_or_null (with rows_per_page = lp): a
  * non-finite unmasked row sets bit 3 of its page's flag word on the way (see evdr_flag_nonfinite). */
-int evdr_l2norm_fwd_split(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps,
+EVDR_API int evdr_l2norm_fwd_split(const float* x, const uint8_t* rowmask_or_null, int64_t rows, int64_t d, float eps,
                           float* y_or_null, float* norm_or_null, uint16_t* planes, uint32_t* amax_bits,
                           uint32_t* pageflags_or_null, int64_t rows_per_page, void* hip_stream);
 
@@ -227,15 +231,15 @@ int evdr_l2norm_fwd_split(const float* x, const uint8_t* rowmask_or_null, int64_
  * top_scores/top_idx (nq, k); rows with n < k are padded with (-inf, -1).
  * workspace_or_null (evdr_topk_workspace bytes; 0 = not needed): lets a few long rows be ranked by many workgroups
  * (per-segment candidates, then a merge) instead of one workgroup per row; same result either way. */
-size_t evdr_topk_workspace(int64_t nq, int64_t n, int k);
-int evdr_topk(const float* scores, const int32_t* idx_map_or_null, int64_t nq, int64_t n,
+EVDR_API size_t evdr_topk_workspace(int64_t nq, int64_t n, int k);
+EVDR_API int evdr_topk(const float* scores, const int32_t* idx_map_or_null, int64_t nq, int64_t n,
               int64_t row_stride, int32_t idx_base, int k,
               float* top_scores, int32_t* top_idx,
               void* workspace_or_null, size_t workspace_bytes, void* hip_stream);
 
 /* A1 + A8 in one call on a prepared corpus: scores land in `workspace` (nq*np floats). */
-size_t evdr_maxsim_topk_workspace(int64_t nq, int64_t np);
-int evdr_maxsim_topk(const uint16_t* Qplanes, const uint16_t* Pplanes,
+EVDR_API size_t evdr_maxsim_topk_workspace(int64_t nq, int64_t np);
+EVDR_API int evdr_maxsim_topk(const uint16_t* Qplanes, const uint16_t* Pplanes,
                      const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
                      int64_t nq, int64_t lq, int64_t np, int64_t lp,
                      int nplanes, int64_t p_stride, int64_t p_plane_stride,
@@ -250,7 +254,7 @@ int evdr_maxsim_topk(const uint16_t* Qplanes, const uint16_t* Pplanes,
  * the one 4-byte store then lands on the host and float(loss) needs no copy launch, only an event behind the call);
  * dscore_or_null (b, n);
  * row_loss: b floats of scratch (device). */
-int evdr_infonce_distill_fwd_bwd(const float* score_s, const float* score_t, int64_t b, int64_t n,
+EVDR_API int evdr_infonce_distill_fwd_bwd(const float* score_s, const float* score_t, int64_t b, int64_t n,
                                  float temperature, float* loss, float* dscore_or_null,
                                  float* row_loss, void* hip_stream);
 
@@ -258,24 +262,27 @@ int evdr_infonce_distill_fwd_bwd(const float* score_s, const float* score_t, int
  * memory, the last one a ticket counter that is ZERO before the first call and is left zero by every call (the last
  * workgroup to finish reduces the per-row losses in a fixed order, so the loss is the same bits as above).  One workspace
  * per stream that may run the call concurrently. */
-int evdr_infonce_distill_fwd_bwd_ws(const float* score_s, const float* score_t, int64_t b, int64_t n,
+EVDR_API int evdr_infonce_distill_fwd_bwd_ws(const float* score_s, const float* score_t, int64_t b, int64_t n,
                                     float temperature, float* loss, float* dscore_or_null,
                                     void* workspace, void* hip_stream);
 
 /* ---- debug hooks: not part of the drop-in surface (tests and A/B measurements only) -----------------------------------
  * The library reads NO environment variable and takes no pointer from one; everything that changes its behaviour comes in
- * through a call.  evdr_debug_set_fwd_variant: force a forward-kernel family for the whole process (0 = default dispatch,
+ * through a call.  Both overrides are THREAD-LOCAL (like evdr_last_error): they apply to the launches the CALLING thread issues
+ * after the call and to no other thread's -- no process-wide mutable state (tests/cabi/cabi_threads.cpp: a thread that forces a
+ * variant does not change what its neighbours dispatch).
+ * evdr_debug_set_fwd_variant: force a forward-kernel family for the calling thread's launches (0 = default dispatch,
  * 1 = flat per-tile ring, 2 = staged kernel without the priority schedule, 10/11 = fp16-plane stage shapes (3 / 4 tiles),
  * 30 = one 8-wave workgroup per CU also for 3-12 queries, 31 = no non-temporal corpus stream, 33 / 34 = non-temporal stream of
  * the fp16-plane forward forced on / off (default: on for >= 128 MiB of planes read by <= 2 query groups), 36 = two queries per wave also
  * for small fp16-plane launches (default: one per wave when 16-query workgroups would number <= 128); all variants compute the same
  * scores -- the test sweep runs each against the oracle); returns the previous value.
- * evdr_debug_set_pages_per_block: pages per workgroup (0 = automatic); returns the previous value.
+ * evdr_debug_set_pages_per_block: pages per workgroup for the calling thread's launches (0 = automatic); returns the previous value.
  * evdr_last_fwd_kernel: host string naming the forward instance the last evdr_maxsim_fwd* / evdr_maxsim_topk call of
  * this thread dispatched (template arguments as in csrc/maxsim_fwd16.hip) -- what bench.py records next to its timing. */
-int         evdr_debug_set_fwd_variant(int variant);
-int         evdr_debug_set_pages_per_block(int pages);
-const char* evdr_last_fwd_kernel(void);
+EVDR_API int         evdr_debug_set_fwd_variant(int variant);
+EVDR_API int         evdr_debug_set_pages_per_block(int pages);
+EVDR_API const char* evdr_last_fwd_kernel(void);
 
 #ifdef __cplusplus
 }

@@ -5,8 +5,11 @@
   libevdr_sentinel_fault.so     the same race under the sentinel                                 -> wrong by ~1e36 wherever it bites
   libevdr_faultwar.so           flat kernel: refill issued IN FRONT of the hand-over (WAR race)  -> overwrites tiles slower waves still read
   libevdr_sentinel_faultwar.so  the same under the sentinel
+  libevdr_faultwar2.so          STAGED two-slot ring (the headline kernel): the whole refill of slot s^1 issued IN FRONT of the hand-over
+                                that retires the slower waves' last ds_reads of that slot (WAR race; round 5)
+  libevdr_sentinel_faultwar2.so the same under the sentinel
 Job A: 256 queries x 2048 pages x 1030 patches (staged kernel; the RAW fault lives in every kernel's hand-over).
-Job B: 256 queries x 4096 pages x 200 patches (7 tiles: the flat 3-slot ring, where the WAR fault lives).
+Job B: 256 queries x 4096 pages x 200 patches (7 tiles: the flat 3-slot ring, where the WAR fault of build 2 lives; build 3's lives in job A's ring).
 Each build runs in a child process (one library handle per process).  What the control shows: how often a real ring race is
 visible WITHOUT the poison (the blind spot of bit-compare stress loops) and WITH it.
 usage: python scratch/sentinel_control.py            (parent: runs the children)
@@ -17,7 +20,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIBS = ["libevdr.so", "libevdr_sentinel.so", "libevdr_fault.so", "libevdr_sentinel_fault.so", "libevdr_faultwar.so", "libevdr_sentinel_faultwar.so"]
+LIBS = ["libevdr.so", "libevdr_sentinel.so", "libevdr_fault.so", "libevdr_sentinel_fault.so", "libevdr_faultwar.so", "libevdr_sentinel_faultwar.so",
+        "libevdr_faultwar2.so", "libevdr_sentinel_faultwar2.so"]
 
 
 def child(libname):
@@ -27,11 +31,11 @@ def child(libname):
     _lib.LIB_PATH = os.path.join(_lib.PKG_DIR, libname)
     from evdr_amd.corpus import PageCorpus
     dev = torch.device("cuda:0")
-    for job, (n, lp) in (("A 2048 x 1030", (2048, 1030)), ("B 4096 x 200 ", (4096, 200))):
+    for job, (n, lp, nq, dt) in (("A 2048 x 1030", (2048, 1030, 256, torch.bfloat16)), ("B 4096 x 200 ", (4096, 200, 256, torch.bfloat16)),
+                                 ("C 512x1030 f32", (512, 1030, 32, torch.float32))):          # C: the fp16-plane staged instance of the teacher forward
         g = torch.Generator(device=dev).manual_seed(5)
-        nq = 256
-        P = torch.nn.functional.normalize(torch.randn((n, lp, 128), generator=g, device=dev), dim=-1).bfloat16()
-        Q = torch.nn.functional.normalize(torch.randn((nq, 32, 128), generator=g, device=dev), dim=-1).bfloat16()
+        P = torch.nn.functional.normalize(torch.randn((n, lp, 128), generator=g, device=dev), dim=-1).to(dt)
+        Q = torch.nn.functional.normalize(torch.randn((nq, 32, 128), generator=g, device=dev), dim=-1).to(dt)
         ref = torch.empty((nq, n), device=dev)
         for lo in range(0, n, 64):                 # plain torch fp32 reference of the same op (bf16 products are exact in fp32)
             sim = torch.einsum("qnd,pmd->qpnm", Q.float(), P[lo:lo + 64].float())
@@ -57,6 +61,9 @@ if __name__ == "__main__":
         child(sys.argv[1])
     else:
         for lib in LIBS:
+            if not os.path.exists(os.path.join(ROOT, "efficient-visual-document-retrieval_amd", lib)):
+                print(f"{lib}: not built, skipped")
+                continue
             r = subprocess.run([sys.executable, os.path.abspath(__file__), lib], cwd=ROOT)
             if r.returncode != 0:
                 print(f"{lib}: child exited with {r.returncode}")

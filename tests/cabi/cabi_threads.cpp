@@ -24,6 +24,8 @@ struct Case {
     std::vector<float> got, alone;
     int rc = 0;
     char err[256] = "";
+    int force_variant = 0;          // > 0: this thread forces a forward-kernel family for ITS launches (thread-local debug hook)
+    char kname[128] = "";           // instance its last threaded launch dispatched
 };
 
 static uint16_t to_bf16(float f) {
@@ -70,6 +72,7 @@ static int score(Case& c, std::vector<float>& into) {
         snprintf(c.err, sizeof(c.err), "%s", evdr_last_error());       // this thread's own error text
         return rc;
     }
+    snprintf(c.kname, sizeof(c.kname), "%s", evdr_last_fwd_kernel());
     if (hipStreamSynchronize(c.st) != hipSuccess) return -1;
     return hipMemcpy(into.data(), c.dout, into.size() * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
@@ -83,12 +86,17 @@ int main() {
     };
     for (size_t i = 0; i < cases.size(); ++i)
         if (setup(cases[i], 100 + (unsigned)i)) { printf("setup failed\n"); return 2; }
+    // the debug overrides are thread-local: thread 1 forces the flat-ring family for its own launches; every other thread must keep
+    // dispatching what the default dispatch picks, and must find its own override still 0 at the end
+    cases[1].force_variant = 1;
     std::atomic<int> go{0};
     std::vector<std::thread> th;
     for (auto& c : cases)
         th.emplace_back([&c, &go] {
             while (!go.load()) {}                                        // all threads leave together: first launches race
+            if (c.force_variant && evdr_debug_set_fwd_variant(c.force_variant) != 0) c.rc = -5;
             for (int it = 0; it < 25 && c.rc == 0; ++it) c.rc = score(c, c.got);
+            if (c.rc == 0 && evdr_debug_set_fwd_variant(0) != c.force_variant) c.rc = -6;      // nobody else touched this thread's override
             // a failing call from this thread must leave ITS text in evdr_last_error (thread-local), whatever the others do
             if (c.rc == 0 && evdr_maxsim_fwd(c.dQ, c.dP, nullptr, nullptr, (float*)c.dout, nullptr, c.nq, c.lq, c.np, c.lp, 64, c.dtype, nullptr,
                                              c.dws, c.wsb, c.st) != EVDR_ERR_SHAPE)
@@ -99,9 +107,23 @@ int main() {
     for (auto& t : th) t.join();
     for (size_t i = 0; i < cases.size(); ++i)
         if (cases[i].rc != 0) { printf("thread %zu failed: rc %d %s\n", i, cases[i].rc, cases[i].err); return 3; }
+    if (evdr_debug_set_fwd_variant(0) != 0) { printf("a worker thread's override leaked into the main thread\n"); return 7; }
     for (size_t i = 0; i < cases.size(); ++i) {
         Case& c = cases[i];
+        char threaded[128];
+        snprintf(threaded, sizeof(threaded), "%s", c.kname);
         if (score(c, c.alone) != 0) { printf("serial call %zu failed: %s\n", i, c.err); return 4; }
+        if (c.force_variant) {
+            // forced family in the thread, default family here: different instances, the same scores to rounding
+            if (strncmp(threaded, "maxsim_fwd16_kernel<", 20) != 0 || strcmp(threaded, c.kname) == 0) {
+                printf("case %zu: forced variant dispatched %s (serial: %s)\n", i, threaded, c.kname);
+                return 8;
+            }
+            for (size_t e = 0; e < c.got.size(); ++e)
+                if (!(c.got[e] - c.alone[e] < 1e-5f && c.alone[e] - c.got[e] < 1e-5f)) { printf("case %zu: forced variant scores differ\n", i); return 5; }
+            continue;
+        }
+        if (strcmp(threaded, c.kname) != 0) { printf("case %zu: dispatched %s next to a thread that forced a variant, %s alone\n", i, threaded, c.kname); return 9; }
         if (memcmp(c.got.data(), c.alone.data(), c.got.size() * 4) != 0) { printf("case %zu: threaded scores differ from the serial ones\n", i); return 5; }
         bool nonzero = false;
         for (float v : c.got) nonzero |= v != 0.f;

@@ -32,6 +32,23 @@ def test_every_declared_symbol_is_exported(lib):
     assert sorted(_lib.SIGNATURES) == names
 
 
+def test_exports_equal_the_header(lib):
+    """`nm -D --defined-only` of libevdr.so == the functions include/evdr.h declares, both ways: the library is built with
+    -fvisibility=hidden and only the EVDR_API entry points are dynamic symbols (no C++-mangled internals, no launch helpers).
+    The only other dynamic symbols allowed are the HIP compiler's own per-translation-unit id words (`__hip_cuid_*`, data)."""
+    import subprocess
+    from evdr_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = [ln.split() for ln in out.splitlines() if ln.strip()]
+    funcs = sorted(name for _addr, kind, name in syms if kind in "TtWw")
+    other = sorted(name for _addr, kind, name in syms if kind not in "TtWw" and not name.startswith("__hip_cuid_"))
+    assert funcs == declared_functions(), (set(funcs) ^ set(declared_functions()))
+    assert other == [], other
+    text = open(os.path.join(ROOT, "include", "evdr.h")).read()
+    for n in declared_functions():                  # every declaration carries the visibility attribute
+        assert re.search(r"EVDR_API\s+[\w \*]+?\b" + n + r"\s*\(", text), n
+
+
 def test_version_and_error_string(lib):
     from evdr_amd import _lib
     assert lib.evdr_version() == _lib.ABI_VERSION == 302
@@ -107,6 +124,27 @@ def test_debug_hooks_round_trip(lib):
     assert lib.evdr_debug_set_fwd_variant(2) == 0 and lib.evdr_debug_set_fwd_variant(0) == 2
     assert lib.evdr_debug_set_pages_per_block(7) == 0 and lib.evdr_debug_set_pages_per_block(0) == 7
     assert lib.evdr_last_fwd_kernel() == b""            # nothing dispatched on this thread yet
+
+
+def test_debug_hooks_are_thread_local(lib):
+    """The overrides are per calling thread (include/evdr.h): what one thread forces is invisible to every other thread, so the
+    library keeps no shared mutable state between concurrent callers."""
+    import threading
+    seen = {}
+
+    def other():
+        seen["variant"] = lib.evdr_debug_set_fwd_variant(11)       # previous value IN THIS THREAD: 0, whatever main set
+        seen["pages"] = lib.evdr_debug_set_pages_per_block(5)
+
+    assert lib.evdr_debug_set_fwd_variant(2) == 0 and lib.evdr_debug_set_pages_per_block(9) == 0
+    try:
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert seen == {"variant": 0, "pages": 0}
+    finally:
+        assert lib.evdr_debug_set_fwd_variant(0) == 2               # and the other thread's 11 / 5 never reached this one
+        assert lib.evdr_debug_set_pages_per_block(0) == 9
 
 
 def test_pair_count_overflow_is_rejected(lib):

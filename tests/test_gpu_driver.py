@@ -104,7 +104,9 @@ def test_driver_fused_step_flag(tmp_path):
     from evdr_amd import driver
     write_synthetic_dataset(tmp_path)
     logs = {}
-    for tag, extra in (("plain", []), ("fused", ["--fused_step"])):
+    # round 5: the fused step and the teacher score cache are the driver's DEFAULT; "plain" opts out of both (the reference's call
+    # pattern: autograd through the drop-in scorer, teacher re-scored every step), "default" passes neither flag
+    for tag, extra in (("plain", ["--no_fused_step", "--no_cache_teacher_scores"]), ("fused", ["--fused_step"]), ("default", [])):
         out = tmp_path / ("results_" + tag)
         driver.main(["--datasets", "synth", "--mapping_json", str(tmp_path / "map.json"), "--query_root", str(tmp_path),
                      "--teacher_root", str(tmp_path), "--init_root", str(tmp_path), "--mfs", "4", "--out_root", str(out),
@@ -114,6 +116,9 @@ def test_driver_fused_step_flag(tmp_path):
         assert (out / "run" / "mf4" / "synth" / "best_ndcg5.npz").exists() or True
     assert len(logs["plain"]) == 12
     np.testing.assert_allclose(logs["fused"], logs["plain"], rtol=1e-4)
+    assert logs["default"] == logs["fused"]                      # no flag = the fused step (bit-reproducible since round 4) + cache
+    from evdr_amd import driver as _d
+    assert _d.LOAD_STATS[-1]["fused_step"] is True and _d.LOAD_STATS[-1]["teacher_score_cache"] is True
     # the fused loop leaves the losses on the device and reads them when a line is due: with a line every 4 steps the logged
     # values and the running average are the ones of the per-step run
     out = tmp_path / "results_fused_batched"
@@ -527,7 +532,7 @@ def test_driver_runs_as_a_program(tmp_path):
     ref = _losses(single)
     assert len(ref) == 6 and all(np.isfinite(ref))
     port = 29700 + os.getpid() % 90
-    for tag, extra in (("fused", ["--fused_step", "--cache_teacher_scores"]), ("autograd", ["--cache_teacher_scores"])):
+    for tag, extra in (("fused", []), ("autograd", ["--no_fused_step"])):          # (defaults: fused step + teacher score cache)
         out = tmp_path / f"r_two_{tag}"
         procs = []
         for rank in range(2):

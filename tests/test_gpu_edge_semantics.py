@@ -494,3 +494,66 @@ def test_small_fp32_launches_take_one_query_per_wave_and_score_the_same_bits():
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4, rtol=0)
         if want_argmax:
             assert torch.equal(arg.cpu().to(torch.int32) & 0xFFFF, warg.to(torch.int32))
+
+
+def test_drop_in_functions_run_under_inference_mode():
+    """torch.inference_mode() tensors track no autograd version counter (`t._version` raises): the per-tensor caches of the
+    drop-in layer (planes made by l2_normalize, prepared pages, the last query batch's planes) must treat them as not cacheable
+    instead of raising -- l2_normalize, normalize_masked, preprocess_queries(device=cuda) and score_multi_vector_masked give the
+    oracle's values there, call after call, on fp32 and on bf16 inputs."""
+    from evdr_amd import ops
+    from evdr_amd.evaluator import retrieval as ER
+    from evdr_amd.utils import preprocess_data as PD
+    g = torch.Generator().manual_seed(91)
+    nq, lq, npg, lp = 11, 17, 23, 75
+    Qraw = torch.randn(nq, lq, 128, generator=g)
+    X = torch.randn(npg, lp, 128, generator=g)
+    qm = torch.rand(nq, lq, generator=g) > 0.2
+    pm = torch.rand(npg, lp, generator=g) > 0.25
+    pm[3] = False
+    want = O.maxsim_masked(O.l2_normalize(Qraw), O.l2_normalize(X * pm.unsqueeze(-1)), qm, pm)
+    ER.forget_prepared()
+    with torch.inference_mode():
+        Q = PD.l2_normalize(Qraw.to(DEV))
+        P = PD.normalize_masked(X.to(DEV), pm.to(DEV))
+        assert Q.is_inference() and P.is_inference()
+        assert ops.tensor_key(P) is None and ops.planes_of(P) is None          # nothing remembered, nothing raised
+        for _ in range(2):                                                     # second call: would have been a cache hit
+            s = ER.score_multi_vector_masked(Q, P, qm.to(DEV), pm.to(DEV))
+            assert (s.cpu() - want).abs().max().item() < 1e-5
+        sb = ER.score_multi_vector_masked(Q.bfloat16(), P.bfloat16(), qm.to(DEV), pm.to(DEV))
+        wb = O.maxsim_masked(Q.bfloat16().float().cpu(), P.bfloat16().float().cpu(), qm, pm)
+        assert (sb.cpu() - wb).abs().max().item() < 1e-4
+        qobj = np.empty(3, dtype=object)
+        for i, n in enumerate((5, 9, 7)):
+            qobj[i] = Qraw[i, :n].numpy()
+        q2, qm2 = PD.preprocess_queries(qobj, None, DEV)
+        assert q2.is_cuda and q2.shape == (3, 9, 128) and qm2.sum().item() == 21
+        assert torch.allclose(q2[1].cpu(), O.l2_normalize(Qraw[1, :9]), atol=1e-6)
+    assert len(ER._PREPARED) == 0 and len(ER._QPLANES) == 0 and len(ops._DERIVED) == 0
+    # outside inference mode the same calls still cache
+    Pn = PD.normalize_masked(X.to(DEV), pm.to(DEV))
+    s = ER.score_multi_vector_masked(PD.l2_normalize(Qraw.to(DEV)), Pn, qm.to(DEV), pm.to(DEV))
+    assert (s.cpu() - want).abs().max().item() < 1e-5 and len(ER._PREPARED) == 1
+    ER.forget_prepared()
+
+
+def test_l2_normalize_keeps_planes_only_for_trainable_pages():
+    """The planes hand-over (l2_normalize -> score_multi_vector_masked without absmax + split passes) is for the reference's
+    TRAINING step, where Psb = l2_normalize(Pbar_param * pmask) is scored by the next call (mainv2_iter_distill_infonce.py:279,286).
+    A tensor normalised without a graph -- the teacher at load time, queries, evaluation under no_grad -- gets no second copy of
+    itself as planes."""
+    from evdr_amd import ops
+    from evdr_amd.utils.preprocess_data import l2_normalize
+    x = torch.randn(6, 40, 128, device=DEV)
+    ops._DERIVED.clear()
+    y = l2_normalize(x)
+    assert ops.planes_of(y) is None and len(ops._DERIVED) == 0
+    xp = x.clone().requires_grad_(True)
+    with torch.no_grad():
+        y = l2_normalize(xp * 1.0)
+    assert ops.planes_of(y) is None
+    y = l2_normalize(xp * 1.0)
+    assert ops.planes_of(y) is not None
+    del y
+    assert len(ops._DERIVED) == 0                           # the planes die with the tensor

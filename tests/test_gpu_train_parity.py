@@ -1,0 +1,35 @@
+"""BASELINE.json configs[4] at the bench's OWN size (B = 32 queries, N = 500 pages, teacher 1030 / student 206 patches, fp32):
+the oracle's restatement of the reference step (/root/reference/mainv2_iter_distill_infonce.py:279-291, criterion.py:56-68)
+and the fused GPU step on the same inputs, compared as a step -- what bench_train.py / bench.py put into their `cpu_baseline`
+records.  N = 500 is the only size that selects the >= 128 MiB non-temporal teacher instance, so this
+pins that instance to the oracle directly."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config4_step_at_bench_size_against_the_oracle():
+    import evdr_amd  # noqa: F401
+    import bench_train as BT
+    torch.set_num_threads(16)
+    dev = torch.device("cuda:0")
+    inp = BT.make_inputs(500, 32, dev)
+    rec = BT.parity_vs_gpu(inp, 500)
+    assert rec["loss_rel_diff_vs_gpu"] <= 1e-5, rec                       # gate: loss rtol 1e-5
+    assert rec["param_max_abs_diff_vs_gpu"] <= 1e-6, rec                  # gate: parameters after one AdamW step, atol 1e-6
+    assert rec["param_max_abs_diff_vs_gpu_where_gradient_above_noise"] <= 1e-6, rec
+    assert rec["teacher_score_max_abs_diff_vs_gpu"] <= 1e-4 and rec["student_score_max_abs_diff_vs_gpu"] <= 1e-4, rec
+    assert rec["teacher_target_mismatches"] == 0 and rec["argmax_mismatches"] == 0, rec
+    assert rec["teacher_kernel"].startswith("maxsim_fwd16s_kernel<2,2,false,4,2,") and rec["teacher_kernel"].endswith(",true>"), rec   # the nt instance
+    # the record bench_train.py prints carries the same fields next to the timed oracle step
+    base = BT.cpu_baseline(inp, 500, reps=1)
+    for key in ("loss_abs_diff_vs_gpu", "param_max_abs_diff_vs_gpu", "argmax_mismatches", "value", "cores", "kind", "sample"):
+        assert key in base, key
+    assert base["loss_abs_diff_vs_gpu"] == rec["loss_abs_diff_vs_gpu"]    # both steps are deterministic

@@ -311,3 +311,26 @@ def test_evaluate_topk_with_repeated_docids_goes_through_the_dict_entry():
     idx = EvalIndex(qrels, qkeys, docids, [1, 3])
     assert not idx.usable
     assert evaluate_topk(idx, ts, ti) == evaluate(qrels, results_from_topk(ts, ti, qkeys, docids), [1, 3])
+
+
+def test_fast_path_defaults_and_their_fallbacks():
+    """`resolve_fast_paths`: no flag = fused step + teacher score cache; --no_* opts out; a cache beyond --teacher_cache_gb is not made
+    and says so; another optimizer than AdamW takes the autograd step by default and refuses an explicit --fused_step."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import driver
+    ap = driver.build_argparser()
+    base = ["--datasets", "d", "--mapping_json", "m.json"]
+    said = []
+    assert driver.resolve_fast_paths(ap.parse_args(base), 25000, 500, said.append) == (True, True) and not said
+    assert driver.resolve_fast_paths(ap.parse_args(base + ["--no_fused_step", "--no_cache_teacher_scores"]), 25000, 500, said.append) == (False, False)
+    assert driver.resolve_fast_paths(ap.parse_args(base + ["--fused_step", "--cache_teacher_scores"]), 25000, 500, said.append) == (True, True)
+    assert not said
+    # 25 000 queries x 100 000 pages x 4 B = 9.3 GiB > the default 8 GiB budget: logged fallback, never silent
+    assert driver.resolve_fast_paths(ap.parse_args(base), 25000, 100000, said.append) == (True, False)
+    assert len(said) == 1 and "teacher score cache" in said[0] and "not made" in said[0]
+    assert driver.resolve_fast_paths(ap.parse_args(base + ["--teacher_cache_gb", "16"]), 25000, 100000, said.append) == (True, True)
+    said.clear()
+    assert driver.resolve_fast_paths(ap.parse_args(base + ["--opt", "adam"]), 100, 10, said.append) == (False, True)
+    assert len(said) == 1 and "AdamW only" in said[0]
+    with pytest.raises(ValueError, match="AdamW only"):
+        driver.resolve_fast_paths(ap.parse_args(base + ["--opt", "adam", "--fused_step"]), 100, 10, said.append)
