@@ -200,7 +200,32 @@ def kernel_rooflines(inp, reps: int = 30):
                                             f"{ins['launches'][role]} steps; step with the events {ins['ms_per_step_with_events']:.4f} ms")
         return entry
 
-    return [both(e, r) for e, r in zip(_entries(mfma_entry, t_kernel, t_ms, s_kernel, s_ms, u_ms, u_bytes), ("teacher", "student", "update"))]
+    out = [both(e, r) for e, r in zip(_entries(mfma_entry, t_kernel, t_ms, s_kernel, s_ms, u_ms, u_bytes), ("teacher", "student", "update"))]
+    for e, r in zip(out, ("teacher", "student", "update")):
+        e["traffic"], e["traffic_source"] = replayed_traffic(r, e["kernel"], N, B)
+        alg = e.get("algorithmic_bytes_per_launch") or {"teacher": N * LT * D * 4, "student": N * LS * D * 4 + B * N * LQ * 2}[r]
+        e.setdefault("algorithmic_bytes_per_launch", alg)
+        e["traffic_over_algorithmic"] = (e["traffic"] / alg) if e["traffic"] else None
+    return out
+
+
+def replayed_traffic(role: str, kernel: str, n_pages: int, batch: int):
+    """HBM-side bytes per launch of one of the step's kernels: PMC counters cannot be read inside this process, so the figure of the
+    committed rocprofv3 --pmc passes (profiles/train_traffic.json, made by scratch/pmc_train.sh + pmc_train_post.py) is REPLAYED --
+    only when it was taken for this kernel instance and step shape; the file and its hash go into the line, (None, None) otherwise."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "train_traffic.json")
+    try:
+        import hashlib
+        raw = open(path, "rb").read()
+        rec = json.loads(raw)
+        ent = rec["kernels"][role]
+        squash = lambda x: "".join(str(x).split())
+        if rec.get("pages") == n_pages and rec.get("batch") == batch and squash(kernel) in squash(ent["kernel"]):
+            return ent["hbm_bytes_per_launch"], {"kind": "replayed rocprofv3 --pmc counters (not measured in this run)", "file": "profiles/train_traffic.json",
+                                                 "sha256": hashlib.sha256(raw).hexdigest()[:16], "round": rec.get("round")}
+    except Exception:
+        pass
+    return None, None
 
 
 def _entries(mfma_entry, t_kernel, t_ms, s_kernel, s_ms, u_ms, u_bytes):
@@ -295,9 +320,12 @@ def parity_vs_gpu(inp, n_pages: int, host_inputs=None):
     parameters after one AdamW update, the teacher's top-1 targets and the student forward's arg-max.  Gates (tests/
     test_gpu_train_parity.py): loss rtol 1e-5, parameters atol 1e-6.  At N = 500 this is the >= 128 MiB `nt` teacher instance
     and the bench's own launch shapes.
-    AdamW's first update is lr * g / (|g| + 1e-8): `param_max_abs_diff_vs_gpu` is over ALL entries; the figure restricted to entries
-    whose oracle gradient is exactly 0 or at least 1e-7 in magnitude (well above AdamW's eps, where the update is sign-like and
-    insensitive to summation noise) is given beside it.
+    The GRADIENT w.r.t. the raw parameter is compared on every entry (atol 1e-6; read back from AdamW's first moment).  AdamW's first
+    update is lr * g / (|g| + 1e-8) -- sign-like: it divides the gradient's summation noise (~4e-7 absolute here, two correct fp32
+    summation orders) by |g|, so the PARAMETERS are compared at atol 1e-6 where the oracle's gradient is exactly 0 or >= 1e-6 in
+    magnitude (97 % of the entries at N = 500; measured <= 2e-7 there), the all-entries figure is reported beside it (up to ~lr / 2
+    where |g| ~ 1e-9), and the update RULE is pinned on EVERY entry by applying torch.optim.AdamW on the host to the GPU's own
+    gradient (`param_max_abs_diff_vs_adamw_of_gpu_gradient_all_entries`, rounding only).
     An arg-max entry counts as a mismatch only if the oracle's own similarities at the two indices differ by more than 1e-6
     (otherwise it is an fp32 tie that two summation orders break differently: `argmax_fp32_ties`)."""
     from evdr_amd import driver
@@ -331,15 +359,22 @@ def parity_vs_gpu(inp, n_pages: int, host_inputs=None):
             live = (qmc.bool()[:, None, :] & pmsc[lo:lo + 64].bool().any(dim=1)[None, :, None]).expand_as(diff)
             mism += int((diff & live & (gap > 1e-6)).sum())
             ties += int((diff & live & (gap <= 1e-6)).sum())
-    comparable = (grad_c == 0) | (grad_c.abs() >= 1e-7)
+    # the GPU's gradient w.r.t. the raw parameter, read back from AdamW's first moment (step 1: exp_avg = (1 - beta1) * g, exact to an ulp)
+    grad_g = student.exp_avg.cpu() / 0.1
+    comparable = (grad_c == 0) | (grad_c.abs() >= 1e-6)
     pdiff = (student.x.cpu() - param_c).abs()
+    # the update RULE on every entry: torch.optim.AdamW applied on the host to the GPU's own gradient must land on the GPU's parameters
+    chk = torch.nn.Parameter(Pbc.clone())
+    chk.grad = grad_g.clone()
+    torch.optim.AdamW([chk], lr=1e-3, weight_decay=1e-2).step()
     return {"parity_sample": f"oracle step vs fused GPU step, same inputs: B={B}, {n_pages} pages, one AdamW update",
             "loss_gpu": float(loss_g), "loss_abs_diff_vs_gpu": abs(float(loss_g) - float(loss_c)),
             "loss_rel_diff_vs_gpu": abs(float(loss_g) - float(loss_c)) / max(abs(float(loss_c)), 1e-30),
-            "param_max_abs_diff_vs_gpu": float(pdiff.max()),                                   # ALL entries
-            "param_max_abs_diff_vs_gpu_where_gradient_above_noise": float(pdiff[comparable].max()),
-            "param_entries_with_gradient_below_noise": int((~comparable).sum()),
-            "grad_max_abs_diff_vs_gpu": None,
+            "grad_max_abs_diff_vs_gpu": float((grad_g - grad_c).abs().max()), "grad_max_abs": float(grad_c.abs().max()),
+            "param_max_abs_diff_vs_gpu": float(pdiff[comparable].max()),
+            "param_compared": f"{int(comparable.sum())} of {comparable.numel()} entries: oracle gradient exactly 0 or >= 1e-6 in magnitude",
+            "param_max_abs_diff_vs_gpu_all_entries": float(pdiff.max()),
+            "param_max_abs_diff_vs_adamw_of_gpu_gradient_all_entries": float((student.x.cpu() - chk.detach()).abs().max()),
             "teacher_score_max_abs_diff_vs_gpu": float((sc_t_g.cpu() - sc_t_c).abs().max()),
             "student_score_max_abs_diff_vs_gpu": float((sc_s_g.cpu() - sc_s_c).abs().max()),
             "teacher_target_mismatches": int((sc_t_g.argmax(dim=1).cpu() != sc_t_c.argmax(dim=1)).sum()),
@@ -383,8 +418,14 @@ def main():
     ap.add_argument("--only", type=str, default="", help="comma list of modes to run (default: all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel repetitions (rocprofv3 runs: the trace then holds the steps' kernels only)")
+    ap.add_argument("--fwd-variant", type=int, default=0,
+                    help="evdr_debug_set_fwd_variant for this process's launches (A/B and counter passes only; 34 = the teacher's corpus "
+                         "stream on the default cache policy instead of non-temporal)")
     a = ap.parse_args()
     import evdr_amd  # noqa: F401
+    if a.fwd_variant:
+        from evdr_amd import _lib as L
+        L.load().evdr_debug_set_fwd_variant(a.fwd_variant)
     kinds = ALL_KINDS + (["eager"] if a.eager else [])
     if a.only:
         kinds = [k for k in kinds if k in a.only.split(",")]
@@ -395,6 +436,7 @@ def main():
     print(json.dumps({"metric": "InfoNCE-distillation steps/sec (mainv2_iter_distill_infonce.py train_one_step)",
                       "value": res[head]["steps_per_sec"] if head else None, "unit": "steps/s", "n_gpus": 1, "higher_is_better": True,
                       "ms_per_step": res[head]["ms_per_step"] if head else None, "mode": head, "data": "synthetic", "vs_baseline": None,
+                      "fwd_variant": a.fwd_variant,
                       **rec}))
 
 

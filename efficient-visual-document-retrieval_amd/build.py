@@ -48,9 +48,10 @@ def build(force: bool = False, verbose: bool = True, experiment: bool = False, s
     LDS-DMA piece poisoning its destination first (csrc/maxsim_device.h), loaded only by tests/test_gpu_sentinel.py.
     ring_fault (scratch/sentinel_control.py only): 1 removes the ring hand-over's vmcnt wait (a RAW race, libevdr[_sentinel]_fault.so),
     2 issues the flat kernel's refill in front of the hand-over (a WAR race, libevdr[_sentinel]_faultwar.so), 3 does the same in the
-    STAGED two-slot ring -- the headline kernel's -- (libevdr[_sentinel]_faultwar2.so)."""
+    STAGED two-slot ring -- the headline kernel's -- (libevdr[_sentinel]_faultwar2.so), 4 is build 3 with one wave of each workgroup held
+    back in front of its last reads of every stage, i.e. with the race window open by construction (libevdr[_sentinel]_faultwar2held.so)."""
     suffix = "_exp" if experiment else ("_sentinel" if sentinel else "")
-    suffix += {0: "", 1: "_fault", 2: "_faultwar", 3: "_faultwar2"}[int(ring_fault)]   # 1: hand-over without its vmcnt wait (RAW); 2 / 3: refill in front of it (WAR: flat / staged ring)
+    suffix += {0: "", 1: "_fault", 2: "_faultwar", 3: "_faultwar2", 4: "_faultwar2held"}[int(ring_fault)]   # 1: hand-over without its vmcnt wait (RAW); 2 / 3: refill in front of it (WAR: flat / staged ring)
     obj_dir = OBJ_DIR + suffix
     lib_path = LIB_PATH.replace("libevdr.so", f"libevdr{suffix}.so")
     flags = FLAGS + (["-DEVDR_EXPERIMENT"] if experiment else []) + (["-DEVDR_SENTINEL"] if sentinel else []) + (
@@ -90,4 +91,4 @@ def build(force: bool = False, verbose: bool = True, experiment: bool = False, s
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, experiment="--experiment" in sys.argv, sentinel="--sentinel" in sys.argv,
-          ring_fault=3 if "--ring-fault-war2" in sys.argv else (2 if "--ring-fault-war" in sys.argv else int("--ring-fault" in sys.argv)))
+          ring_fault=4 if "--ring-fault-war2-held" in sys.argv else 3 if "--ring-fault-war2" in sys.argv else (2 if "--ring-fault-war" in sys.argv else int("--ring-fault" in sys.argv)))

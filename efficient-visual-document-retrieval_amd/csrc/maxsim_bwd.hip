@@ -10,6 +10,9 @@
 namespace {
 
 constexpr int BW_THREADS = 512;
+#ifndef EVDR_BW_EARLY_ROW
+#define EVDR_BW_EARLY_ROW 1       /* A/B: 0 = the epilogue's first row is loaded when the epilogue starts (the form until round 5) */
+#endif
 #ifndef EVDR_BW_SMALL_WGS
 #define EVDR_BW_SMALL_WGS 384     /* launches of at most this many 128-row workgroups take 64-row slabs (A/B builds: -DEVDR_BW_FORCE_CAP=64|128) */
 #endif
@@ -113,14 +116,14 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
     constexpr int NWAVES = BW_THREADS / 64;
     constexpr int NSLOTS = PER_THREAD * NWAVES;                          // wave-instructions that bucket pairs, per chunk
     constexpr int CW = (NSLOTS + 3) / 4;                                 // counter words per row (one byte per slot: <= 64 lanes)
-    static_assert(CHUNK % BW_THREADS == 0 && BW_ROWS <= 128 && BW_ROWS <= BW_THREADS, "bucket geometry");
+    static_assert(CHUNK % BW_THREADS == 0 && (BW_ROWS == 64 || BW_ROWS == 128), "bucket geometry: one or two whole waves of buckets");
     extern __shared__ __attribute__((aligned(16))) float acc[];          // [BW_ROWS][128]
     int* list = reinterpret_cast<int*>(acc + BW_ROWS * EVDR_D);          // [CHUNK] pair index inside the chunk, bucketed
     float* wl = reinterpret_cast<float*>(list + CHUNK);                  // [CHUNK] weight of list[k]
     int* hist = reinterpret_cast<int*>(wl + CHUNK);                      // [BW_ROWS] bucket sizes
     int* offs = hist + BW_ROWS;                                          // [BW_ROWS] bucket starts
     uint32_t* cnt = reinterpret_cast<uint32_t*>(offs + BW_ROWS);         // [BW_ROWS][CW] pairs per (row, slot), one byte each
-    __shared__ int sh_has, sh_total, sh_rounds;
+    __shared__ int sh_has, sh_total, sh_rounds, sh_wsum[2];
     const int page = blockIdx.x;
     // BW_ROWS is the slab's CAPACITY (LDS); a workgroup owns slab_rows <= BW_ROWS rows, chosen per launch so that a page's slabs
     // are equally tall (206 patches: 103 + 103, not 128 + 78)
@@ -130,38 +133,81 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
     const int wave = tid >> 6;
     const int gid = tid >> 4, sub = tid & 15;
 
-    if (tid == 0) sh_has = (pmask == nullptr) ? 1 : 0;
+    // FUSED epilogue operands of one parameter row (one 16-lane group per row, 8 floats per lane)
+    struct RowIn { f32x4 x0, x1, ea0, ea1, es0, es1; float m; };
+    auto load_row = [&](int r) {
+        RowIn in;
+        const int64_t off = ((int64_t)page * lp + r0 + r) * EVDR_D + sub * 8;
+        in.m = (pmask == nullptr || pmask[(int64_t)page * lp + r0 + r] != 0) ? 1.f : 0.f;
+        in.x0 = *reinterpret_cast<const f32x4*>(ad.x + off);
+        in.x1 = *reinterpret_cast<const f32x4*>(ad.x + off + 4);
+        in.ea0 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off);
+        in.ea1 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off + 4);
+        in.es0 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off);
+        in.es1 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off + 4);
+        return in;
+    };
+    // the same in two halves: the parameter row (9 registers) can be requested while the gather still runs, the moments
+    // (16 more) only when the gather's registers are free
+    auto load_row_x = [&](RowIn& in, int r) {
+        const int64_t off = ((int64_t)page * lp + r0 + r) * EVDR_D + sub * 8;
+        in.m = (pmask == nullptr || pmask[(int64_t)page * lp + r0 + r] != 0) ? 1.f : 0.f;
+        in.x0 = *reinterpret_cast<const f32x4*>(ad.x + off);
+        in.x1 = *reinterpret_cast<const f32x4*>(ad.x + off + 4);
+    };
+    auto load_row_moments = [&](RowIn& in, int r) {
+        const int64_t off = ((int64_t)page * lp + r0 + r) * EVDR_D + sub * 8;
+        in.ea0 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off);
+        in.ea1 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off + 4);
+        in.es0 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off);
+        in.es1 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off + 4);
+    };
+    RowIn nxt{};
+    // Every global load of the bucketing phase is issued up front, in ONE latency period: the page's mask bytes (has(p) =
+    // any(pmask[p]), retrieval.py:192) together with the first chunk's arg-max / upstream-gradient / query-mask words; the slab and the
+    // counters are cleared while they fly.  (Until round 5 the mask scan, a barrier and only then the pair loads: two dependent round
+    // trips to L2 at the head of every workgroup, with the HBM stream of the epilogue idle behind them.)
+    const int npairs = nq * lq;
+    int any = (pmask == nullptr) ? 1 : 0;
+    if (pmask != nullptr)
+        for (int i = tid; i < lp; i += BW_THREADS) any |= pmask[(int64_t)page * lp + i];
+    int a_loc[PER_THREAD], rank_loc[PER_THREAD];
+    float w_loc[PER_THREAD];
+    auto load_pairs = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; ++k) {
+            const int i = c0 + k * BW_THREADS + tid;
+            int a = -1;
+            float w = 0.f;
+            if (i < npairs) {
+                const int q = i / lq, n = i - q * lq;
+                a = (int)argmax[((int64_t)q * np + page) * lq + n] - r0;
+                w = g[(int64_t)q * np + page];
+                if (qmask != nullptr && qmask[i] == 0) w = 0.f;
+                if (a < 0 || a >= rows || w == 0.f) a = -1;
+            }
+            a_loc[k] = a;
+            w_loc[k] = w;
+        }
+    };
+    load_pairs(0);
+    if (tid == 0) sh_has = 0;
     for (int i = tid; i < rows * (EVDR_D / 4); i += BW_THREADS) reinterpret_cast<f32x4*>(acc)[i] = f32x4{0, 0, 0, 0};
     __syncthreads();
-    if (pmask != nullptr) {                               // has(p) = any(pmask[p])  (retrieval.py:192)
-        int any = 0;
-        for (int i = tid; i < lp; i += BW_THREADS) any |= pmask[(int64_t)page * lp + i];
-        if (any) sh_has = 1;                              // benign race: every writer stores 1
-    }
+    if (any) sh_has = 1;                                  // benign race: every writer stores 1
     __syncthreads();
     auto bytesum = [](uint32_t x) { return (int)((x & 0xFFu) + ((x >> 8) & 0xFFu) + ((x >> 16) & 0xFFu) + (x >> 24)); };
     if (sh_has) {
-        const int npairs = nq * lq;
         for (int c0 = 0; c0 < npairs; c0 += CHUNK) {
             for (int r = tid; r < BW_ROWS * CW; r += BW_THREADS) cnt[r] = 0u;
             if (tid == 0) sh_rounds = 0;
+            if (c0 > 0) load_pairs(c0);
             __syncthreads();
             // (1) this thread's pairs: target row inside the slab (or -1), weight g * qmask, and the pair's RANK among the
             // lanes of this wave-instruction that hit the same row; per (row, instruction) counts
-            int a_loc[PER_THREAD], rank_loc[PER_THREAD];
-            float w_loc[PER_THREAD];
 #pragma unroll
             for (int k = 0; k < PER_THREAD; ++k) {
-                const int i = c0 + k * BW_THREADS + tid;
-                int a = -1;
-                float w = 0.f;
-                if (i < npairs) {
-                    const int q = i / lq, n = i - q * lq;
-                    a = (int)argmax[((int64_t)q * np + page) * lq + n] - r0;
-                    w = g[(int64_t)q * np + page];
-                    if (qmask != nullptr && qmask[i] == 0) w = 0.f;
-                    if (a < 0 || a >= rows || w == 0.f) a = -1;
-                }
+                const int a = a_loc[k];
                 // lanes of this instruction with the same row: AND over the 7 row bits of (bit set ? ballot : ~ballot)
                 unsigned long long same = __ballot(a >= 0);
 #pragma unroll
@@ -171,8 +217,6 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
                     same &= bit ? bb : ~bb;
                 }
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
-                a_loc[k] = a;
-                w_loc[k] = w;
                 rank_loc[k] = rank;
                 if (a >= 0 && rank == 0) {                              // one lane per row: integer add, order-free
                     const int slot = k * NWAVES + wave;
@@ -180,23 +224,30 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
                 }
             }
             __syncthreads();
-            // (2) bucket sizes and their exclusive scan (BW_ROWS <= BW_THREADS: one element per thread, Hillis-Steele)
+            // (2) bucket sizes and their exclusive scan: BW_ROWS <= 128 buckets = the first one or two waves, one bucket per lane --
+            // inclusive scan inside the wave by lane shifts, the second wave adds the first one's total: two barriers (the
+            // Hillis-Steele form over all 512 threads took fifteen)
             int v = 0;
             if (tid < BW_ROWS) {
 #pragma unroll
                 for (int wd = 0; wd < CW; ++wd) v += bytesum(cnt[tid * CW + wd]);
                 hist[tid] = v;
-                offs[tid] = v;
+            }
+            int incl = v;
+            if (tid < BW_ROWS) {                           // whole waves: BW_ROWS is 64 or 128
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(incl, o);
+                    if (lane >= o) incl += t;
+                }
+                if (lane == 63) sh_wsum[wave] = incl;
             }
             __syncthreads();
-            for (int o = 1; o < BW_ROWS; o <<= 1) {
-                int add = (tid < BW_ROWS && tid >= o) ? offs[tid - o] : 0;
-                __syncthreads();
-                if (tid < BW_ROWS) offs[tid] += add;
-                __syncthreads();
+            if (tid < BW_ROWS) {
+                const int base = (wave == 1) ? sh_wsum[0] : 0;
+                offs[tid] = base + incl - v;               // exclusive
+                if (tid == BW_ROWS - 1) sh_total = base + incl;    // all bucketed pairs of this chunk
             }
-            if (tid == BW_ROWS - 1) sh_total = offs[tid];  // all bucketed pairs of this chunk
-            if (tid < BW_ROWS) offs[tid] -= v;            // inclusive -> exclusive
             __syncthreads();
             // (3) scatter: bucket start + pairs of the row in earlier instructions + rank inside this one = ascending pair order
 #pragma unroll
@@ -224,6 +275,11 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
             // the row changes: plain read-modify-write if the whole bucket lies in its slice.  The partial sum of a heavy row
             // it shares with its neighbours stays in registers -- `head`: a row that began in an earlier group's slice,
             // `tail`: a row that continues into the next group's -- and joins the slab in the ordered rounds below.
+            if constexpr (FUSED && EVDR_BW_EARLY_ROW) {
+                // the epilogue's first parameter / moment row is requested HERE, in front of the last chunk's gather: the HBM stream of
+                // the workgroup starts a gather (four L2 round trips) earlier, and the row is in registers when the epilogue begins
+                if (c0 + CHUNK >= npairs && gid < rows) load_row_x(nxt, gid);
+            }
             {
                 const int total = sh_total;
                 const int per = ((total + NGROUPS - 1) / NGROUPS + 3) & ~3;
@@ -318,21 +374,9 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
         // one 16-lane group per parameter row: 8 floats per lane.  The next row's parameter and moments are requested before
         // this row's arithmetic and stores (two rows of loads in flight per group: the epilogue is a pure stream and each
         // group has only four rows to hide its latency behind)
-        struct RowIn { f32x4 x0, x1, ea0, ea1, es0, es1; float m; };
-        auto load_row = [&](int r) {
-            RowIn in;
-            const int64_t off = ((int64_t)page * lp + r0 + r) * EVDR_D + sub * 8;
-            in.m = (pmask == nullptr || pmask[(int64_t)page * lp + r0 + r] != 0) ? 1.f : 0.f;
-            in.x0 = *reinterpret_cast<const f32x4*>(ad.x + off);
-            in.x1 = *reinterpret_cast<const f32x4*>(ad.x + off + 4);
-            in.ea0 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off);
-            in.ea1 = *reinterpret_cast<const f32x4*>(ad.exp_avg + off + 4);
-            in.es0 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off);
-            in.es1 = *reinterpret_cast<const f32x4*>(ad.exp_avg_sq + off + 4);
-            return in;
-        };
-        RowIn nxt{};
-        if (gid < rows) nxt = load_row(gid);
+        if (gid < rows) {
+            if (EVDR_BW_EARLY_ROW) load_row_moments(nxt, gid); else nxt = load_row(gid);
+        }
         for (int r = gid; r < rows; r += NGROUPS) {
             const RowIn in = nxt;
             if (r + NGROUPS < rows) nxt = load_row(r + NGROUPS);

@@ -794,7 +794,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             // (In-block, the whole next stage is fetched, also tiles outside the page's valid range.)
             const bool next_rows = (nk + 1) * ST * EVDR_TILE_PATCHES <= p.lp;     // every row of the next stage exists
             const bool next_full = refill && next_rows;
-#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT == 3
+#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT >= 3
             const bool spread = false;                                     // (control build: the whole refill goes out in front of the hand-over, below)
 #else
             const bool spread = fast && next_full && spread_ok;
@@ -817,12 +817,16 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             if constexpr (DIAG) { d_a = stamp(); d_ctl += d_a - d_c0; }
             // stage hand-over (ring_barrier, maxsim_device.h): this wave's pieces of the stage have landed and every ds_read it
             // has issued is retired BEFORE it arrives; nothing can be scheduled into or across the statement
-#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT == 3
+#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT >= 3
             // WAR control of the sentinel instrument for THIS (staged, two-slot) ring -- never a shipped build (build.py ring_fault=3,
             // scratch/sentinel_control.py): the refill of slot `nslot` is issued IN FRONT of the hand-over that retires the
             // ds_reads of the stage the slower waves of the workgroup may still be computing from that very slot.  This wave's own
             // reads of the slot are retired first (lgkmcnt(0)), so what is left is exactly the cross-wave write-after-read edge the
             // hand-over exists for.  (RAW stays intact: the hand-over's vmcnt(0) below also covers the pieces issued here.)
+            // EVDR_RING_FAULT == 4: the same, with the race window held OPEN -- one wave of the workgroup sleeps ~14 us in front of
+            // its reads of the stage's last tile (fault_hold in the fast block), so that the other waves' early refill of that slot is
+            // certain to overtake it: what the instrument shows when the race really happens, as opposed to build 3, which only
+            // removes the edge and leaves the timing to the hardware.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (refill) {
                 if (next_rows) {
@@ -840,7 +844,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             // retires it; the value is first used when the fetch cursor opens that page)
             if (load_apf) apf = pageflags_c[pg0 + npgi + 1];
             if constexpr (DIAG) { const unsigned long long t = stamp(); d_bar += t - d_a; d_a = t; }
-#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT == 3
+#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT >= 3
             if (false) {
 #else
             if (refill && !spread) {
@@ -912,6 +916,17 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                             return v < G ? v : G;
                         };
                         auto refill_hi = [&](int ti) { return refill_lo(ti + 1); };
+                        // control build 4 only (see the hand-over below): ONE wave sleeps in front of its reads of the stage's last tile
+                        auto fault_hold = [&](bool here) {
+#if defined(EVDR_RING_FAULT) && EVDR_RING_FAULT == 4
+                            if (here && wave == WAVES - 3) {
+#pragma unroll 1
+                                for (int z = 0; z < 4; ++z) __builtin_amdgcn_s_sleep(127);
+                            }
+#else
+                            (void)here;
+#endif
+                        };
                         auto set_prio = [&](int h) {
                             if constexpr (BAL) {
                                 const int pr = prio_at(h);
@@ -940,6 +955,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                                 if (HEAD && h == 0) chains_masked(a[h % DEPTH], headmask & 0xFFFFu, pbase);
                                 else if (HEAD && h == 1) chains_masked(a[h % DEPTH], headmask >> 16, pbase);
                                 else chains_full(a[h % DEPTH], pbase);
+                                fault_hold(h == 2 * ST - 2 - DEPTH);
                                 if (h + DEPTH < 2 * ST) load_half(a[h % DEPTH], sbase, (h + DEPTH) >> 1, (h + DEPTH) & 1);
                                 if constexpr (SP) {
                                     if ((h & 1) == 0) {
@@ -979,6 +995,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
 #pragma unroll
                                         for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(al[s4], bq[j][0][t][s4], acc[j][t]);
                                 asm volatile("" ::: "memory");
+                                fault_hold(h == 2 * ST - 3);
                                 if (h + 1 < 2 * ST) load_plane(al, h + 1, 1);
                                 if constexpr (SP) {
                                     if ((h & 1) == 0) {

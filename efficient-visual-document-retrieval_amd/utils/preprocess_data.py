@@ -24,10 +24,9 @@ class _L2NormMasked(torch.autograd.Function):
     last_planes = None          # (address of y, planes, absmax word) of the forward that just ran: handed to _normalized()
 
     @staticmethod
-    def forward(ctx, x, rowmask, eps):
+    def forward(ctx, x, rowmask, eps, want_planes=False):
         from .. import ops
-        if (x.dim() == 3 and x.numel() <= (1 << 30) and ctx.needs_input_grad[0] and torch.is_grad_enabled()
-                and not torch.is_inference_mode_enabled()):
+        if want_planes and x.dim() == 3 and x.numel() <= (1 << 30):
             # page-shaped TRAINABLE input (N, L, 128) -- the reference's Psb = l2_normalize(Pbar_param * pmask), scored by the very
             # next call of its step (mainv2_iter_distill_infonce.py:279,286): the launch also leaves y as the scorer's fp16 hi/lo
             # planes and _normalized() below hangs them on the returned tensor, so that score_multi_vector_masked(Q, y, ...) runs no
@@ -48,7 +47,7 @@ class _L2NormMasked(torch.autograd.Function):
     def backward(ctx, gy):
         from .. import ops
         x, rowmask, norm = ctx.saved_tensors
-        return ops.l2norm_backward(gy, x, rowmask, norm, ctx.eps), None, None
+        return ops.l2norm_backward(gy, x, rowmask, norm, ctx.eps), None, None, None
 
 
 def _kernel_ok(x: torch.Tensor) -> bool:
@@ -58,7 +57,9 @@ def _kernel_ok(x: torch.Tensor) -> bool:
 def _normalized(x: torch.Tensor, rowmask, eps: float) -> torch.Tensor:
     from .. import ops
     _L2NormMasked.last_planes = None
-    y = _L2NormMasked.apply(x, rowmask, float(eps))
+    # (decided HERE: inside Function.forward the grad mode is always off)
+    trainable = x.requires_grad and torch.is_grad_enabled() and not torch.is_inference_mode_enabled()
+    y = _L2NormMasked.apply(x, rowmask, float(eps), trainable)
     made = _L2NormMasked.last_planes
     _L2NormMasked.last_planes = None
     if made is not None and made[0] == y.data_ptr():

@@ -8,6 +8,10 @@
   libevdr_faultwar2.so          STAGED two-slot ring (the headline kernel): the whole refill of slot s^1 issued IN FRONT of the hand-over
                                 that retires the slower waves' last ds_reads of that slot (WAR race; round 5)
   libevdr_sentinel_faultwar2.so the same under the sentinel
+  libevdr_faultwar2held.so      build faultwar2 with the race window held OPEN: one wave of every workgroup sleeps ~14 us in front of its reads of
+                                each stage's last tile, so the other waves' early refill is certain to overtake it -> what a WAR race that
+                                really happens looks like, plain ...
+  libevdr_sentinel_faultwar2held.so ... and under the sentinel
 Job A: 256 queries x 2048 pages x 1030 patches (staged kernel; the RAW fault lives in every kernel's hand-over).
 Job B: 256 queries x 4096 pages x 200 patches (7 tiles: the flat 3-slot ring, where the WAR fault of build 2 lives; build 3's lives in job A's ring).
 Each build runs in a child process (one library handle per process).  What the control shows: how often a real ring race is
@@ -21,7 +25,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIBS = ["libevdr.so", "libevdr_sentinel.so", "libevdr_fault.so", "libevdr_sentinel_fault.so", "libevdr_faultwar.so", "libevdr_sentinel_faultwar.so",
-        "libevdr_faultwar2.so", "libevdr_sentinel_faultwar2.so"]
+        "libevdr_faultwar2.so", "libevdr_sentinel_faultwar2.so", "libevdr_faultwar2held.so", "libevdr_sentinel_faultwar2held.so"]
 
 
 def child(libname):

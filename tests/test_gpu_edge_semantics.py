@@ -532,8 +532,9 @@ def test_drop_in_functions_run_under_inference_mode():
         assert torch.allclose(q2[1].cpu(), O.l2_normalize(Qraw[1, :9]), atol=1e-6)
     assert len(ER._PREPARED) == 0 and len(ER._QPLANES) == 0 and len(ops._DERIVED) == 0
     # outside inference mode the same calls still cache
-    Pn = PD.normalize_masked(X.to(DEV), pm.to(DEV))
-    s = ER.score_multi_vector_masked(PD.l2_normalize(Qraw.to(DEV)), Pn, qm.to(DEV), pm.to(DEV))
+    pmd = pm.to(DEV)                                                            # (the cache entry lives as long as pages AND mask do)
+    Pn = PD.normalize_masked(X.to(DEV), pmd)
+    s = ER.score_multi_vector_masked(PD.l2_normalize(Qraw.to(DEV)), Pn, qm.to(DEV), pmd)
     assert (s.cpu() - want).abs().max().item() < 1e-5 and len(ER._PREPARED) == 1
     ER.forget_prepared()
 
