@@ -11,7 +11,7 @@ namespace {
 
 constexpr int BW_THREADS = 512;
 #ifndef EVDR_BW_EARLY_ROW
-#define EVDR_BW_EARLY_ROW 1       /* A/B: 0 = the epilogue's first row is loaded when the epilogue starts (the form until round 5) */
+#define EVDR_BW_EARLY_ROW 1       /* A/B: 0 = the epilogue's first row is loaded when the epilogue starts (the form until round 5); 1 = its parameter part in front of the gather; 2 = at the kernel's head */
 #endif
 #ifndef EVDR_BW_SMALL_WGS
 #define EVDR_BW_SMALL_WGS 384     /* launches of at most this many 128-row workgroups take 64-row slabs (A/B builds: -DEVDR_BW_FORCE_CAP=64|128) */
@@ -191,6 +191,11 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
         }
     };
     load_pairs(0);
+    if constexpr (FUSED && EVDR_BW_EARLY_ROW == 2) {
+        // ... and the epilogue's first PARAMETER row with them (9 registers carried through the bucketing; the moments, 16 more,
+        // follow when the gather's registers are free): the workgroup's HBM stream starts with its first instruction
+        if (gid < rows) load_row_x(nxt, gid);
+    }
     if (tid == 0) sh_has = 0;
     for (int i = tid; i < rows * (EVDR_D / 4); i += BW_THREADS) reinterpret_cast<f32x4*>(acc)[i] = f32x4{0, 0, 0, 0};
     __syncthreads();
@@ -275,9 +280,9 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
             // the row changes: plain read-modify-write if the whole bucket lies in its slice.  The partial sum of a heavy row
             // it shares with its neighbours stays in registers -- `head`: a row that began in an earlier group's slice,
             // `tail`: a row that continues into the next group's -- and joins the slab in the ordered rounds below.
-            if constexpr (FUSED && EVDR_BW_EARLY_ROW) {
-                // the epilogue's first parameter / moment row is requested HERE, in front of the last chunk's gather: the HBM stream of
-                // the workgroup starts a gather (four L2 round trips) earlier, and the row is in registers when the epilogue begins
+            if constexpr (FUSED && EVDR_BW_EARLY_ROW == 1) {
+                // the epilogue's first parameter row is requested HERE, in front of the last chunk's gather: the HBM stream of the
+                // workgroup starts a gather (four L2 round trips) earlier, and the row is in registers when the epilogue begins
                 if (c0 + CHUNK >= npairs && gid < rows) load_row_x(nxt, gid);
             }
             {
@@ -637,7 +642,25 @@ __global__ void __launch_bounds__(256) infonce_row_kernel(const float* __restric
     uint32_t tbest = 0u;
     float smax = -__builtin_inff();
     int tidx = 0;
-    for (int64_t i = tid; i < n; i += 256) {
+    // the row is read from memory ONCE: a thread's first KEEP elements of s / temp stay in registers for the two later passes (all
+    // of them for n <= 1024: a training batch scores 500 pages); the same values in the same order as re-reading them
+    constexpr int KEEP = 4;
+    float z[KEEP];
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const int64_t i = tid + 256 * k;
+        z[k] = (i < n) ? s[i] / temp : -__builtin_inff();
+    }
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const int64_t i = tid + 256 * k;
+        if (i < n) {
+            const uint32_t tk = nan_max_key(t[i]);
+            if (tk > tbest) { tbest = tk; tidx = (int)i; }
+            smax = fmaxf(smax, z[k]);
+        }
+    }
+    for (int64_t i = tid + 256 * KEEP; i < n; i += 256) {
         const uint32_t tk = nan_max_key(t[i]);
         if (tk > tbest) { tbest = tk; tidx = (int)i; }
         smax = fmaxf(smax, s[i] / temp);
@@ -660,7 +683,13 @@ __global__ void __launch_bounds__(256) infonce_row_kernel(const float* __restric
     smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float sum = 0.f;
-    for (int64_t i = tid; i < n; i += 256) sum += expf(s[i] / temp - smax);
+    float e[KEEP];
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        e[k] = expf(z[k] - smax);
+        if (tid + 256 * k < n) sum += e[k];
+    }
+    for (int64_t i = tid + 256 * KEEP; i < n; i += 256) sum += expf(s[i] / temp - smax);
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
@@ -670,7 +699,12 @@ __global__ void __launch_bounds__(256) infonce_row_kernel(const float* __restric
     if (dscore != nullptr) {
         float* d = dscore + (int64_t)blockIdx.x * n;
         const float inv_sum = 1.f / sum;
-        for (int64_t i = tid; i < n; i += 256) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int64_t i = tid + 256 * k;
+            if (i < n) d[i] = (e[k] * inv_sum - ((int)i == tidx ? 1.f : 0.f)) * inv_tb;
+        }
+        for (int64_t i = tid + 256 * KEEP; i < n; i += 256) {
             const float pr = expf(s[i] / temp - smax) * inv_sum;
             d[i] = (pr - ((int)i == tidx ? 1.f : 0.f)) * inv_tb;
         }
