@@ -718,6 +718,46 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     const bool spread_ok = p.inblock_refill != 0;
     int slot = 0;
     bool page_open = true;                              // the compute cursor is at the first stage of its page
+    // ---- page-end stores, deferred by one hand-over.  A finished page's score / arg-max words are kept in registers and stored
+    // right BEHIND the next stage hand-over instead of in front of it: global stores count on vmcnt like the LDS-DMA pieces, so a
+    // store issued at the page end made the next hand-over's vmcnt(0) wait for its write acknowledgement (~1 us from L2) with every
+    // wave of the workgroup parked -- 4 us of a 76-us student forward (scratch/fwd_store_ab.py: the launch without any store).
+    // Behind the hand-over the acknowledgement has a whole stage of matrix work to arrive in.  Same values, same addresses.
+    // Only the fp16-plane instances (the training step's forwards: a 206-patch page is two stages, every second hand-over follows a
+    // page end): their straight-line blocks leave the registers for it.  The bf16 instances sit at 256 VGPRs with the per-page values
+    // live across the block (deferring there spills: 1-3 VGPRs in the QW = 2 / 4 instances), and a 1030-patch bf16 page amortises the
+    // acknowledgement over four 512-MFMA stages (launch without stores: -0.3 %); they store at the page end as before.
+    constexpr bool DEFER = (NPL == 2);
+    int pend_page = -1;                                  // wave-uniform: the page whose stores are pending (-1: none)
+    float pend_cs[QW];
+    int pend_bi[QW][2];
+    auto store_page = [&](int spage, const float (&scs)[QW], const int (&sbi)[QW][2]) {
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+            if constexpr (ARGMAX) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    // (opaque per page: otherwise the 64-bit per-lane output offsets of all (query, token) slots are hoisted out of
+                    // the page loop -- 16 VGPRs that end up spilled, with their reloads landing inside the MFMA blocks)
+                    int tok = 16 * t + c;
+                    asm volatile("" : "+v"(tok));
+                    if (g == 0 && tok < p.lq && qreal[j] >= 0)
+                        p.argmax[((int64_t)qreal[j] * p.np + spage) * p.lq_total + p.tok0 + tok] = (uint16_t)sbi[j][t];
+                }
+            }
+            if (lane == 0 && qreal[j] >= 0) {
+                float* o = p.out + (int64_t)qreal[j] * p.out_stride + spage;
+                if (p.accumulate) atomicAdd(o, scs[j]);
+                else *o = scs[j];
+            }
+        }
+    };
+    auto flush_pending = [&]() {
+        if constexpr (!DEFER) return;
+        if (pend_page < 0) return;
+        store_page(pend_page, pend_cs, pend_bi);
+        pend_page = -1;
+    };
     // per-page values of the compute cursor, decoded once when the page is opened
     uint32_t pflags = 0u;
     int va = 0, vb = 0, first_masked = 0, khi = 0;
@@ -863,6 +903,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                     issue_stage(npgi, nk, ntlo, nthi, nslot);
                 }
             }
+            flush_pending();                                             // the previous page's stores: behind the hand-over and the refill
             if constexpr (DIAG) { const unsigned long long t = stamp(); d_ref += t - d_a; d_a = t; }
             const char* sbase = a_lane + slot * STAGE_BYTES;
             const int nt = (k == spp - 1) ? p.ntiles - t0 : ST;          // tiles in this stage (ST + 1 in an extended last stage)
@@ -1189,23 +1230,35 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                         continue;
                     }
                     if constexpr (ARGMAX) {
-                        if (g == 0 && tok < p.lq && qreal[j] >= 0)
-                            p.argmax[((int64_t)qreal[j] * p.np + page) * p.lq_total + p.tok0 + tok] = (uint16_t)bi;
+                        if constexpr (DEFER) {
+                            pend_bi[j][t] = bi;                            // stored by flush_pending(), behind the next hand-over
+                        } else {
+                            if (g == 0 && tok < p.lq && qreal[j] >= 0)
+                                p.argmax[((int64_t)qreal[j] * p.np + page) * p.lq_total + p.tok0 + tok] = (uint16_t)bi;
+                        }
                     }
                     cs += v * has * qwt[j][t];
                 }
                 if (p.per_token) continue;
                 cs = row16_sum(cs);
                 if ((pflags & 1u) && ((pflags & 8u) || qbad[j] != 0u)) cs = opaque_nan();
-                if (lane == 0 && qreal[j] >= 0) {
-                    float* o = p.out + (int64_t)qreal[j] * p.out_stride + page;
-                    if (p.accumulate) atomicAdd(o, cs);
-                    else *o = cs;
+                if constexpr (DEFER) {
+                    pend_cs[j] = cs;
+                } else {
+                    if (lane == 0 && qreal[j] >= 0) {
+                        float* o = p.out + (int64_t)qreal[j] * p.out_stride + page;
+                        if (p.accumulate) atomicAdd(o, cs);
+                        else *o = cs;
+                    }
                 }
+            }
+            if constexpr (DEFER) {
+                if (!p.per_token) pend_page = page;
             }
         }
         if constexpr (DIAG) d_fin += stamp() - d_a;
     }
+    flush_pending();                                    // the workgroup's last page
     if constexpr (DIAG) {
         if (p.dbg != nullptr && lane == 0 && blockIdx.x < 4096) {
             unsigned long long* o = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;

@@ -48,7 +48,7 @@ def kernels(lines):
         m = re.match(r"^(_Z\w+):", lines[i])
         if m:
             j = i + 1
-            while "s_endpgm" not in lines[j]:
+            while not lines[j].startswith(".Lfunc_end"):     # (not the first s_endpgm: an early-exit path may carry its own)
                 j += 1
             name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
             name = name.replace("(anonymous namespace)::", "").replace("(EvdrFwdParams)", "").replace("void ", "")
