@@ -552,7 +552,9 @@ def _run_datasets(args, writer, loader, read_dataset, mapping, device, rank, wor
                 logger, tb = get_logger(out_dir)
                 cfg = out_dir / "config.json"
                 if not cfg.exists():
-                    cfg.write_text(json.dumps({"dataset": dataset, "mf": mf, **vars(args)}, ensure_ascii=False, indent=2))
+                    cfg.write_text(json.dumps({"dataset": dataset, "mf": mf, **vars(args),
+                                               "fast_paths": {"fused_step": use_fused, "teacher_score_cache": use_cache}},
+                                              ensure_ascii=False, indent=2))
             else:                                                   # the other ranks compute the same numbers and stay silent
                 import logging
                 logger, tb = logging.getLogger(f"evdr.rank{rank}"), None
