@@ -12,10 +12,12 @@ for p in paths:
     lib.evdr_maxsim_fwd_prepared.argtypes = L.SIGNATURES["evdr_maxsim_fwd_prepared"][1]
     libs.append(lib)
 stream = torch.cuda.current_stream(dev).cuda_stream
+ONLY = os.environ.get("AB_ONLY", "")
 def unit(*s, g): return torch.nn.functional.normalize(torch.randn(*s, device=dev, generator=g), dim=-1)
 for name, (nq, npg, lp, f32, argmax, reps) in {"student fwd + argmax 32x500x206 f32": (32, 500, 206, True, True, 40), "teacher fwd 32x500x1030 f32": (32, 500, 1030, True, False, 20),
                                                "student shard 32x63x206 f32": (32, 63, 206, True, True, 40),
                                                "headline-like 1024x4000x1030 bf16": (1024, 4000, 1030, False, False, 5), "32x20000x1030 bf16": (32, 20000, 1030, False, False, 10)}.items():
+    if ONLY and ONLY not in name: continue
     g = torch.Generator(device=dev).manual_seed(7)
     Q, P = unit(nq, 32, 128, g=g), unit(npg, lp, 128, g=g)
     if f32:
