@@ -57,10 +57,11 @@ def test_world_size_mismatch_and_missing_gpus_fail_loudly():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """The last committed bench line (profiles/r04_bench_n1.json, written by `python bench.py` on an MI355X) carries every field
+    """The last committed bench line (profiles/r05_bench_n1.json, written by `python bench.py` on an MI355X) carries every field
     the driver's contract names, the roofline object of the dominant kernel, the CPU baseline, the training-step, evaluation and
-    phase records (round 3) and, since round 4, kernel times taken inside the timed steps and inside the training step."""
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")))
+    phase records (round 3), since round 4 kernel times taken inside the timed steps and inside the training step, and since
+    round 5 the counter traffic of the three training kernels and the configs[4] step parity at N = 500 in the training record."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in rec, key
@@ -81,10 +82,10 @@ def test_committed_bench_line_follows_the_contract():
         t = json.loads(raw)
         assert t["kernel"] == r["kernel"] and t["queries"] == rec["config"]["queries_per_step"] and t["pages_per_gpu"] == rec["config"]["pages"]
         assert r["traffic"] == t["hbm_bytes_per_launch"] >= r["algorithmic_bytes_per_launch"]
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_summary.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_summary.json")))
         assert pmc["hbm_bytes_per_launch"] == t["hbm_bytes_per_launch"]
     assert "INSIDE the timed region" in r["kernel_ms_basis"] or "inside the timed region" in r["kernel_ms_basis"]
-    stats = open(os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.csv")).read().splitlines()
+    stats = open(os.path.join(ROOT, "profiles", "r05_bench_kernel_stats.csv")).read().splitlines()
     top = next(ln for ln in stats[1:] if "maxsim_fwd16s_kernel<4, 1, false, 8" in ln)
     avg_ms = float(top.split('",')[1].split(",")[2]) / 1e6
     assert abs(avg_ms - r["kernel_ms"]) < 0.01 * r["kernel_ms"]           # rocprofv3's average agrees with the HIP-event time of the line
@@ -101,9 +102,21 @@ def test_committed_bench_line_follows_the_contract():
         assert abs(r_["frac"] - r_["executed_flop_per_launch"] / (r_["kernel_ms"] * 1e-3) / 1e12 / 2500.0) < 1e-9
         assert abs(r_["algorithmic_tflops"] - r_["algorithmic_flop_per_launch"] / (r_["kernel_ms"] * 1e-3) / 1e12) < 1e-6
     assert t["roofline"][2]["bound"] == "hbm" and t["cpu_baseline"]["kind"] == "port" and t["cpu_baseline"]["sample_pages"] <= 500
+    # round 5: the timed step is the production path; every training kernel's roofline carries the replayed counter traffic (close to
+    # its algorithmic bytes: nothing is re-read); the oracle step at the bench's own N = 500 is compared with the fused GPU step
+    assert "PageCorpus.topk" in rec["timed_path"]
+    for e_ in t["roofline"]:
+        assert e_["traffic_source"]["file"] == "profiles/train_traffic.json" and 1.0 <= e_["traffic_over_algorithmic"] < 1.15, e_["role"]
+    import hashlib
+    raw_t = open(os.path.join(ROOT, "profiles", "train_traffic.json"), "rb").read()
+    assert hashlib.sha256(raw_t).hexdigest().startswith(t["roofline"][0]["traffic_source"]["sha256"])
+    cb = t["cpu_baseline"]
+    assert cb["sample_pages"] == 500 and cb["loss_rel_diff_vs_gpu"] <= 1e-5 and cb["grad_max_abs_diff_vs_gpu"] <= 1e-6
+    assert cb["param_max_abs_diff_vs_gpu"] <= 1e-6 and cb["param_max_abs_diff_vs_adamw_of_gpu_gradient_all_entries"] <= 1e-6
+    assert cb["argmax_mismatches"] == 0 and cb["teacher_target_mismatches"] == 0
     # round 4: every training kernel is stated alone AND inside the step; the in-step figures add up to less than the step, and each
     # agrees within 3 % ... 8 % box noise with the rocprofv3 trace of the timed steps of the same call
-    trace = json.load(open(os.path.join(ROOT, "profiles", "r04_train_fused_trace_exclusive.json")))
+    trace = json.load(open(os.path.join(ROOT, "profiles", "r05_train_fused_trace_exclusive.json")))
     assert trace["last_calls_per_kernel"] == 30
     assert sum(v["overlap_with_predecessor_avg_us"] for v in trace["kernels"].values()) < 1.0      # intervals of one queue do not overlap
     keys = ("maxsim_fwd16s_kernel<2, 2, false", "maxsim_fwd16s_kernel<2, 2, true", "maxsim_bwd_kernel")
@@ -114,7 +127,7 @@ def test_committed_bench_line_follows_the_contract():
     import re
     with_events = float(re.search(r"step with the events ([0-9.]+) ms", t["roofline"][0]["kernel_ms_in_step_basis"]).group(1))
     assert sum(in_step) < with_events < 1.10 * t["results"]["fused"]["ms_per_step"]
-    prof_step = json.load(open(os.path.join(ROOT, "profiles", "r04_prof_train_line.json")))["results"]["fused"]["ms_per_step"]
+    prof_step = json.load(open(os.path.join(ROOT, "profiles", "r05_prof_train_line.json")))["results"]["fused"]["ms_per_step"]
     # per step: the step's own kernels (30 calls each in the 30 timed steps) plus the once-per-epoch preparation (driver.EpochBatches:
     # two gathers and one split launch per epoch, a few calls in the whole trace) spread over the steps
     per_step_us = sum(v["plain_avg_us"] * min(v["calls"], 30) / 30.0 for v in trace["kernels"].values())
@@ -133,6 +146,6 @@ def test_committed_bench_line_follows_the_contract():
     assert set(ph["rank0"]) == {"score_ms", "topk_ms"} and abs(ph["rank0"]["score_ms"] - r["kernel_ms"]) < 0.02 * r["kernel_ms"]
     assert rec["dist"]["ranks_seen"] == 1 and rec["dist"]["pages_per_rank"] == rec["config"]["pages"]
     # and the standalone training bench of the same call agrees with the line's record within box noise
-    bt = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_train.json")))
+    bt = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_train.json")))
     for mode in ("call_pattern", "fused", "fused_cached"):
         assert abs(bt["results"][mode]["ms_per_step"] - t["results"][mode]["ms_per_step"]) < 0.08 * bt["results"][mode]["ms_per_step"]
