@@ -6,7 +6,12 @@ name=$1; shift
 src=maxsim_fwd16
 if [ "$1" = "--src" ]; then src=$2; shift 2; fi
 R=$(cd "$(dirname "$0")/.." && pwd); P=$R/efficient-visual-document-retrieval_amd
-python3 -c "import sys; sys.path.insert(0, '$R'); import evdr_amd; from evdr_amd import build; build.build(verbose=False)"
+# The other five objects are the PRODUCT build's (build/*.o).  This script never rebuilds or relinks the in-tree libevdr.so: until round 5 it
+# called build.build() first, which silently rebuilt the product library from whatever the working tree held -- a half-edited experimental
+# source reached one fuzz call that way (profiles/r05_experiments.txt, item 3).  Build the product first, on a clean tree.
+for o in maxsim_fwd maxsim_fwd16 maxsim_bwd topk prep evdr_capi; do
+    [ -f "$P/build/$o.o" ] || { echo "missing $P/build/$o.o: build the product library first (python -m evdr_amd.build) on a clean tree" >&2; exit 1; }
+done
 mkdir -p $R/scratch/ab /tmp/evdr_variant_$name
 extra=""; [ "$src" = "maxsim_fwd16" ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -fno-honor-nans -std=c++17 -Wall -Wno-unused-function $extra "$@" \
