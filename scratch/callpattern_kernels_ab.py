@@ -17,6 +17,7 @@ Q = torch.nn.functional.normalize(torch.randn(B, 32, 128, device=dev, generator=
 ss = torch.randn(B, N, device=dev, generator=g) * 3; st = torch.randn(B, N, device=dev, generator=g) * 3
 gy = torch.randn(N, Ls, 128, device=dev, generator=g) * 1e-3
 ea, es = torch.zeros_like(x), torch.zeros_like(x)
+WS = ops.infonce_workspace(B, dev)
 def jobs():
     y, norm, planes, amax = ops.l2norm_forward(x, pm, 1e-12, want_planes=True)
     tm, pf = ops.pack_pmask(pm, N, Ls, dev)
@@ -29,6 +30,7 @@ def jobs():
         "split_f32(Q)": lambda: ops.split_f32(Q),
         "student fwd+argmax": lambda: ops.maxsim_forward_prepared(qp, qa, planes, amax, qm, tm, pf, want_argmax=True),
         "infonce (two-launch form)": lambda: ops.infonce_distill(ss, st, 0.1, want_grad=True),
+        "infonce (one-launch form)": lambda: ops.infonce_distill(ss, st, 0.1, want_grad=True, ws=WS),
         "maxsim_bwd (dP)": lambda: ops.maxsim_backward(gs, Q, qm, pm, arg, N, Ls),
         "l2norm_bwd": lambda: ops.l2norm_backward(gy, x, pm, norm, 1e-12),
         "adamw_step": lambda: ops.adamw_step(gy, x, ea, es, 1e-3, (0.9, 0.999), 1e-8, 1e-2, 1),
