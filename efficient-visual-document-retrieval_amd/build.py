@@ -14,6 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libevdr.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
+VARIANT_DIR = os.path.join(os.path.dirname(PKG_DIR), "scratch", "_variants")     # control / experiment builds (never loaded by the package)
 
 SOURCES = ["maxsim_fwd.hip", "maxsim_fwd16.hip", "maxsim_bwd.hip", "topk.hip", "prep.hip", "evdr_capi.hip"]
 HEADERS = [os.path.join(CSRC, "evdr_common.h"), os.path.join(CSRC, "maxsim_device.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "evdr.h")]
@@ -43,17 +44,28 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True, experiment: bool = False, sentinel: bool = False,
           ring_fault: int = 0) -> str:
     """Compile every HIP source for gfx950 and link libevdr.so; returns its path.  experiment=True builds
-    libevdr_exp.so with -DEVDR_EXPERIMENT instead (the stamped diagnostic kernel instances used by scratch/; never
+    scratch/_variants/libevdr_exp.so with -DEVDR_EXPERIMENT instead (the stamped diagnostic kernel instances used by scratch/; never
     loaded by the package).  sentinel=True builds libevdr_sentinel.so with -DEVDR_SENTINEL: the same kernels with every
     LDS-DMA piece poisoning its destination first (csrc/maxsim_device.h), loaded only by tests/test_gpu_sentinel.py.
-    ring_fault (scratch/sentinel_control.py only): 1 removes the ring hand-over's vmcnt wait (a RAW race, libevdr[_sentinel]_fault.so),
+    ring_fault (scratch/sentinel_control.py only; output under scratch/_variants/, never in the package directory): 1 removes the ring hand-over's vmcnt wait (a RAW race, libevdr[_sentinel]_fault.so),
     2 issues the flat kernel's refill in front of the hand-over (a WAR race, libevdr[_sentinel]_faultwar.so), 3 does the same in the
     STAGED two-slot ring -- the headline kernel's -- (libevdr[_sentinel]_faultwar2.so), 4 is build 3 with one wave of each workgroup held
     back in front of its last reads of every stage, i.e. with the race window open by construction (libevdr[_sentinel]_faultwar2held.so)."""
     suffix = "_exp" if experiment else ("_sentinel" if sentinel else "")
     suffix += {0: "", 1: "_fault", 2: "_faultwar", 3: "_faultwar2", 4: "_faultwar2held"}[int(ring_fault)]   # 1: hand-over without its vmcnt wait (RAW); 2 / 3: refill in front of it (WAR: flat / staged ring)
-    obj_dir = OBJ_DIR + suffix
-    lib_path = LIB_PATH.replace("libevdr.so", f"libevdr{suffix}.so")
+    if ring_fault or experiment:
+        # deliberately broken / instrumented-for-experiments builds never sit beside the product library: objects and library go to
+        # scratch/_variants/ (git-ignored; control scripts load them by absolute path), so that no option of the test suite can
+        # pick one up from the package directory
+        # (ring_fault builds one level deeper, in faults/, which .gpurunignore lists: they reach a GPU box only when a control run
+        # takes that line out on purpose)
+        vdir = os.path.join(VARIANT_DIR, "faults") if ring_fault else VARIANT_DIR
+        os.makedirs(vdir, exist_ok=True)
+        obj_dir = os.path.join(vdir, "build" + suffix)
+        lib_path = os.path.join(vdir, f"libevdr{suffix}.so")
+    else:
+        obj_dir = OBJ_DIR + suffix
+        lib_path = LIB_PATH.replace("libevdr.so", f"libevdr{suffix}.so")
     flags = FLAGS + (["-DEVDR_EXPERIMENT"] if experiment else []) + (["-DEVDR_SENTINEL"] if sentinel else []) + (
         [f"-DEVDR_RING_FAULT={int(ring_fault)}"] if ring_fault else [])
     os.makedirs(obj_dir, exist_ok=True)

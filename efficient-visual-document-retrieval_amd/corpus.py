@@ -98,24 +98,28 @@ class PageCorpus:
         the MaxSim launch -- the ONLY difference between the timed step of the bench and what `ShardedRetriever.search` runs."""
         dev = ops._require_cuda(Q)
         nq, lq, _ = Q.shape
+        if not (1 <= k <= L.EVDR_TOPK_MAX):               # before the early returns: an invalid k never passes silently
+            raise ValueError(f"k={k} outside 1..{L.EVDR_TOPK_MAX}")
         if nq == 0:
             return (torch.empty((0, k), dtype=torch.float32, device=dev), torch.empty((0, k), dtype=torch.int32, device=dev))
         if self.n_pages == 0:
             return (torch.full((nq, k), float("-inf"), dtype=torch.float32, device=dev), torch.full((nq, k), -1, dtype=torch.int32, device=dev))
-        if not (1 <= k <= L.EVDR_TOPK_MAX):
-            raise ValueError(f"k={k} outside 1..{L.EVDR_TOPK_MAX}")
         qp, qamax = self._query_planes(Q)
-        if self._ws is None or self._ws.shape != (nq, self.n_pages) or self._ws.device != dev:
-            self._ws = torch.empty((nq, self.n_pages), dtype=torch.float32, device=dev)      # allocated once per (corpus, batch size)
+        # the score block is a FLAT buffer that only grows (410 MB at 1024 x 100k): a short last batch, or alternating batch sizes,
+        # view its head instead of reallocating it
+        need = nq * self.n_pages
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty((need,), dtype=torch.float32, device=dev)
+        ws = self._ws[:need].view(nq, self.n_pages)
         ev = None
         if self.score_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        ops.maxsim_forward_prepared(qp, qamax, self.planes, self.amax, qmask, self.tilemask, self.pageflags, out=self._ws)
+        ops.maxsim_forward_prepared(qp, qamax, self.planes, self.amax, qmask, self.tilemask, self.pageflags, out=ws)
         if ev is not None:
             ev[1].record()
             self.score_events.append(ev)
-        return ops.topk(self._ws, k, idx_base=self.idx_base)
+        return ops.topk(ws, k, idx_base=self.idx_base)
 
 
 # ---- candidate exchange ---------------------------------------------------------------------------

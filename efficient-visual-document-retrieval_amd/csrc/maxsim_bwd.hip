@@ -380,7 +380,17 @@ __global__ void __launch_bounds__(BW_THREADS) maxsim_bwd_kernel(const float* __r
         // this row's arithmetic and stores (two rows of loads in flight per group: the epilogue is a pure stream and each
         // group has only four rows to hide its latency behind)
         if (gid < rows) {
-            if (EVDR_BW_EARLY_ROW) load_row_moments(nxt, gid); else nxt = load_row(gid);
+            if (EVDR_BW_EARLY_ROW) {
+                // the early request of the parameter row sits inside the gather loop (EARLY_ROW == 1): a workgroup that never
+                // enters it -- a page without a valid patch (sh_has == 0), or a zero-gradient step with no pairs at all -- loads the
+                // row here, otherwise x would be the zeros of `RowIn nxt{}` and the decay / update would overwrite the parameter
+                // (workgroup-uniform condition: no register carried through the gather)
+                const bool have_x = (EVDR_BW_EARLY_ROW == 2) || (sh_has != 0 && npairs > 0);
+                if (!have_x) load_row_x(nxt, gid);
+                load_row_moments(nxt, gid);
+            } else {
+                nxt = load_row(gid);
+            }
         }
         for (int r = gid; r < rows; r += NGROUPS) {
             const RowIn in = nxt;

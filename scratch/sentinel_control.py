@@ -32,7 +32,9 @@ def child(libname):
     import torch
     import evdr_amd  # noqa: F401
     from evdr_amd import _lib
-    _lib.LIB_PATH = os.path.join(_lib.PKG_DIR, libname)
+    # product + sentinel twin live in the package directory; every control build under scratch/_variants/ (absolute path:
+    # tests/conftest.py --evdr-lib refuses them, nothing but this script loads one)
+    _lib.LIB_PATH = os.path.join(_lib.PKG_DIR if libname in ("libevdr.so", "libevdr_sentinel.so") else os.path.join(ROOT, "scratch", "_variants", "faults"), libname)
     from evdr_amd.corpus import PageCorpus
     dev = torch.device("cuda:0")
     for job, (n, lp, nq, dt) in (("A 2048 x 1030", (2048, 1030, 256, torch.bfloat16)), ("B 4096 x 200 ", (4096, 200, 256, torch.bfloat16)),

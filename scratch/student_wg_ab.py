@@ -4,7 +4,7 @@ experiment build, interleaved repeats; every variant must reproduce variant 0's 
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); import evdr_amd
 from evdr_amd import _lib as L
-L.LIB_PATH = os.path.join(L.PKG_DIR, "libevdr_exp.so")
+L.LIB_PATH = os.path.join(os.path.dirname(L.PKG_DIR), "scratch", "_variants", "libevdr_exp.so")
 from evdr_amd import ops
 dev = torch.device("cuda:0"); torch.manual_seed(0); lib = L.load()
 def unit(*s): return torch.nn.functional.normalize(torch.randn(*s, device=dev), dim=-1)

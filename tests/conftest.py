@@ -24,6 +24,9 @@ def pytest_configure(config):
     if lib:
         import evdr_amd  # noqa: F401
         from evdr_amd import _lib
+        if os.path.basename(lib) not in ("libevdr.so", "libevdr_sentinel.so"):
+            # control / experiment builds (scratch/_variants/) hold deliberately racing kernels: never through the suite
+            raise pytest.UsageError(f"--evdr-lib accepts libevdr.so or libevdr_sentinel.so only (got {lib})")
         path = os.path.join(_lib.PKG_DIR, os.path.basename(lib))
         if not os.path.exists(path):
             raise pytest.UsageError(f"--evdr-lib: {path} does not exist (python -m evdr_amd.build --sentinel)")

@@ -359,6 +359,51 @@ def test_update_kernel_emits_next_planes(dev, npg, lp, nq, lq):
     assert float(x[~pm].abs().max() if (~pm).any() else 0.0) == 0.0   # masked rows never move
 
 
+@pytest.mark.parametrize("case", ["no_pairs", "empty_page"])
+@pytest.mark.parametrize("lp", [37, 206])
+def test_update_kernel_rows_without_gradient_follow_torch_adamw(dev, case, lp):
+    """The fused update on rows it has NO gradient for -- a zero-gradient step (nq = 0: g / Q / argmax may be NULL,
+    include/evdr.h) and a page without a valid patch whose masked rows hold non-zero parameters AND non-zero moments --
+    against torch.optim.AdamW fed the same gradient (zero there) from the same seeded state: decay + moment update, never
+    a parameter rebuilt from zeros (the early parameter-row request of the kernel sits inside the gather loop, which such
+    workgroups never enter).  Moments are seeded directly (step 2 of an optimiser), so that no update is sign-like."""
+    from evdr_amd import ops
+    gen = torch.Generator().manual_seed(4100 + lp)
+    npg, nq, lq = 5, 6, 32
+    x0 = (torch.randn(npg, lp, 128, generator=gen) * 0.7).to(dev)          # NOT pre-multiplied by the mask
+    ea0 = (torch.randn(npg, lp, 128, generator=gen) * 1e-3).to(dev)
+    es0 = (torch.rand(npg, lp, 128, generator=gen) * 1e-5 + 1e-7).to(dev)
+    pm = (torch.rand(npg, lp, generator=gen) > 0.3)
+    pm[0] = True
+    pm[2] = False                                                           # a page without a valid patch
+    pm = pm.to(dev)
+    n = 0 if case == "no_pairs" else nq
+    Q = torch.nn.functional.normalize(torch.randn(nq, lq, 128, generator=gen), dim=-1).to(dev)[:n]
+    g = (torch.randn(nq, npg, generator=gen) * 1e-2).to(dev)[:n]
+    arg = torch.randint(0, lp, (nq, npg, lq), generator=gen).to(torch.int16).to(dev)[:n]
+    hyper = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+
+    x, ea, es = x0.clone(), ea0.clone(), es0.clone()
+    ops.maxsim_backward_adamw(g, Q, None, pm, arg, x, ea, es, hyper["lr"], hyper["betas"], hyper["eps"], hyper["weight_decay"], 2)
+
+    xr = x0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([xr], **hyper)
+    opt.state[xr] = {"step": torch.tensor(1.0), "exp_avg": ea0.clone(), "exp_avg_sq": es0.clone()}
+    xm = xr * pm.unsqueeze(-1)
+    y = xm / (xm.norm(dim=-1, keepdim=True) + 1e-12)
+    y.backward(ops.maxsim_backward(g, Q, None, pm, arg, npg, lp) if n else torch.zeros_like(x0))
+    opt.step()
+    want = (xr.detach(), opt.state[xr]["exp_avg"], opt.state[xr]["exp_avg_sq"])
+
+    quiet = torch.ones(npg, lp, dtype=torch.bool, device=dev) if n == 0 else ~pm      # rows without a gradient
+    assert bool(quiet[2].all())
+    for a, b, tol in zip((x, ea, es), want, (2e-7, 1e-9, 1e-11)):
+        np.testing.assert_allclose(a[quiet].cpu().numpy(), b[quiet].cpu().numpy(), atol=tol, rtol=2e-6)
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=50 * tol, rtol=1e-4)
+    moved = (x - x0).abs()[quiet]
+    assert float(moved.max()) < 0.02 and float((x[quiet] - x0[quiet] * (1 - 1e-5)).abs().max()) < 0.02   # decayed, not rebuilt from zero
+
+
 @pytest.mark.parametrize("qs,ps", [(1.0, 1.0), (4096.0, 1.0 / 8192.0), (1e-3, 37.5), (250.0, 250.0)])
 def test_a1_fp32_path_any_magnitude(dev, ER, qs, ps):
     """fp32 inputs far from unit norm (the per-tensor power-of-two scaling of the fp16 planes): scores, argmax and the

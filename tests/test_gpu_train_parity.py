@@ -25,7 +25,7 @@ def test_config4_step_at_bench_size_against_the_oracle():
     assert rec["loss_rel_diff_vs_gpu"] <= 1e-5, rec                       # gate: loss rtol 1e-5
     assert rec["grad_max_abs_diff_vs_gpu"] <= 1e-6, rec                   # gate: Pbar.grad atol 1e-6, every entry
     assert rec["param_max_abs_diff_vs_gpu"] <= 1e-6, rec                  # gate: parameters after one AdamW step, atol 1e-6, where |g| >= 1e-6 or g == 0
-    assert int(rec["param_compared"].split()[0]) >= 0.95 * 500 * 206 * 128, rec
+    assert int(rec["param_compared"].split()[0]) >= 0.965 * 500 * 206 * 128, rec    # observed 97.3 %: the narrowed gate covers (almost) all of the tensor; the rest is gated through the gradient and the update rule
     assert rec["param_max_abs_diff_vs_adamw_of_gpu_gradient_all_entries"] <= 1e-6, rec      # the update rule itself, every entry
     assert rec["param_max_abs_diff_vs_gpu_all_entries"] <= 1.1e-3, rec    # nowhere more than one full AdamW step (lr = 1e-3) apart
     assert rec["teacher_score_max_abs_diff_vs_gpu"] <= 1e-4 and rec["student_score_max_abs_diff_vs_gpu"] <= 1e-4, rec
