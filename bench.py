@@ -190,7 +190,7 @@ def extras(dev, corpus_pages: torch.Tensor, args):
     from evdr_amd.evaluator.retrieval import CustomRetrievalEvaluator
     # cpu_pages = 500: the oracle step at the bench's OWN size (about 2.5 s of host work), so that its `cpu_baseline` also carries
     # the step-level parity of configs[4] at N = 500 (loss / parameters / arg-max against the fused GPU step on the same inputs)
-    train = bench_train.measure(pages=500, batch=32, steps=30, warmup=15, kinds=["call_pattern", "fused", "fused_cached"],
+    train = bench_train.measure(pages=500, batch=32, steps=30, warmup=15, kinds=["call_pattern", "call_pattern_cached", "fused", "fused_cached"],
                                 cpu_pages=500, cpu_reps=1, dev=dev)
     n = min(500, corpus_pages.shape[0])
     pages = corpus_pages[:n]

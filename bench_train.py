@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 LT, LS, LQ, D = 1030, 206, 32, 128
 MFMA_F16_PEAK, MFMA_F32_PEAK, HBM_PEAK = 2500.0, 157.3, 8000.0    # TFLOP/s dense fp16/bf16, TFLOP/s fp32 MFMA, GB/s (MI355X_MICROARCH.md)
 PLANE_PRODUCTS = 3                                                 # lo*hi + hi*lo + hi*hi per fp32 product (csrc/maxsim_fwd16.hip)
-ALL_KINDS = ["call_pattern", "call_pattern_torch_adamw", "resident", "cached", "fused", "fused_cached", "fused_nosync", "fused_cached_nosync", "fused_graph",
+ALL_KINDS = ["call_pattern", "call_pattern_cached", "call_pattern_torch_adamw", "resident", "cached", "fused", "fused_cached", "fused_nosync", "fused_cached_nosync", "fused_graph",
              "fused_cached_graph", "fused_overlap", "fused_overlap_nosync", "fused_stepprep", "fused_stepprep_nosync"]
 EPOCH = 64                                                         # batches per epoch of the benchmark's query set (64 * B queries)
 
@@ -69,7 +69,14 @@ def time_mode(inp, kind: str, steps: int, warmup: int):
     # the scripts take their optimizer from utils.set_optimizer (mainv2_iter_distill_infonce.py:127): the drop-in's is AdamW on a
     # one-pass update kernel; "call_pattern_torch_adamw" keeps torch's own foreach AdamW for the A/B
     opt = torch.optim.AdamW([param], lr=1e-3, weight_decay=1e-2) if kind == "call_pattern_torch_adamw" else set_optimizer("adamw", param, 1e-3, 1e-2)
-    cached = kind in ("cached", "fused_cached", "fused_cached_graph", "fused_cached_nosync")
+    cached = kind in ("cached", "fused_cached", "fused_cached_graph", "fused_cached_nosync", "call_pattern_cached")
+    # "call_pattern_cached": the reference's step, unmodified, with ONE extra line in the re-export shim:
+    # evaluator.retrieval.enable_score_cache() -- the frozen teacher's score rows are then kept per query row on the device
+    from evdr_amd.evaluator import retrieval as _R
+    _R.disable_score_cache()
+    if kind == "call_pattern_cached":
+        _R.enable_score_cache(2 << 30)
+        kind = "call_pattern"
     stepprep = "_stepprep" in kind
     kind = kind.replace("_stepprep", "")
     use_epoch = kind in ("fused", "fused_cached", "fused_nosync", "fused_cached_nosync") and not stepprep
@@ -130,7 +137,11 @@ def time_mode(inp, kind: str, steps: int, warmup: int):
         last = step(i)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
-    return {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "last_loss": float(last.item()) if torch.is_tensor(last) else last}
+    rec = {"ms_per_step": ms, "steps_per_sec": 1e3 / ms, "last_loss": float(last.item()) if torch.is_tensor(last) else last}
+    if _R.score_cache_stats(sync=False)["budget"]:
+        rec["score_cache"] = _R.score_cache_stats()
+        _R.disable_score_cache()
+    return rec
 
 
 def kernel_rooflines(inp, reps: int = 30):
@@ -401,6 +412,7 @@ def measure(pages: int = 500, batch: int = 32, steps: int = 50, warmup: int = 25
                        "batch_queries": batch, "teacher_patches": LT, "student_patches": LS, "steps": steps, "warmup": warmup},
             "dtype": "f32 (fp16 hi/lo split MFMA)",
             "modes": {"call_pattern": "the drop-in functions called exactly like the reference's train_one_step (autograd; the optimizer is what utils.set_optimizer returns: AdamW on the one-pass update kernel)",
+                      "call_pattern_cached": "the same unmodified step after evaluator.retrieval.enable_score_cache() (one line in the re-export shim): the frozen teacher's score rows come from the device-side per-query-row cache after the first epoch",
                       "call_pattern_torch_adamw": "the same with torch.optim.AdamW's own (foreach) step",
                       "fused": "float(loss) returned every step, like the reference's train_one_step (one host wait per step, for the loss only: it is copied out before the update kernel is launched)",
                       "fused_nosync": "what driver.py's --fused_step loop does between log lines: losses stay on the device until a line is due",

@@ -26,6 +26,11 @@ SIGNATURES = {
     "evdr_maxsim_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
     "evdr_maxsim_fwd_prepared": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64,
                                            _vp, _vp, _vp, _vp]),
+    "evdr_maxsim_fwd_prepared_subset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_int, _i64, _i64,
+                                                  _vp, _vp, _vp, _vp, _vp]),
+    "evdr_qcache_workspace": (_sz, [_i64]),
+    "evdr_maxsim_fwd_prepared_cached": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_int, _i64, _i64, _vp, _vp,
+                                                  _vp, _sz, _vp]),
     "evdr_maxsim_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     "evdr_maxsim_bwd_q_workspace": (_sz, [_i64, _i64, _i64, _i64]),
     "evdr_maxsim_bwd_q": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
@@ -52,13 +57,20 @@ SIGNATURES = {
 }
 
 
+class EvdrQCache(C.Structure):
+    """include/evdr.h `EvdrQCache`: plain host struct of device pointers + geometry (evaluator/retrieval.py builds one per cached tensor)."""
+    _fields_ = [("slots", _vp), ("n_slots", _i64), ("ent_hash", _vp), ("ent_k", _vp), ("ent_q", _vp), ("ent_mask", _vp),
+                ("ent_scores", _vp), ("n_entries", _vp), ("capacity", _i64), ("row_bytes", _i64), ("lq", _i64), ("np", _i64),
+                ("hash_mask", C.c_uint64)]
+
+
 class EvdrError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"libevdr status {code}: {msg}")
         self.code = code
 
 
-ABI_VERSION = 302                  # EVDR_VERSION_NUM of csrc/evdr_common.h these signatures belong to
+ABI_VERSION = 303                  # EVDR_VERSION_NUM of csrc/evdr_common.h these signatures belong to
 
 _lib: Optional[C.CDLL] = None
 

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libevdr.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 VARIANT_DIR = os.path.join(os.path.dirname(PKG_DIR), "scratch", "_variants")     # control / experiment builds (never loaded by the package)
 
-SOURCES = ["maxsim_fwd.hip", "maxsim_fwd16.hip", "maxsim_bwd.hip", "topk.hip", "prep.hip", "evdr_capi.hip"]
+SOURCES = ["maxsim_fwd.hip", "maxsim_fwd16.hip", "maxsim_bwd.hip", "topk.hip", "prep.hip", "qcache.hip", "evdr_capi.hip"]
 HEADERS = [os.path.join(CSRC, "evdr_common.h"), os.path.join(CSRC, "maxsim_device.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "evdr.h")]
 # -fno-honor-nans: lets fmaxf chains fold to v_max3_f32 without canonicalising moves (infinities are kept)
 # -fvisibility=hidden: the dynamic symbol table holds the EVDR_API entry points of include/evdr.h and nothing else

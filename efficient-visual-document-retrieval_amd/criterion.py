@@ -8,10 +8,31 @@ import torch
 from . import ops
 
 
+# Workspaces of the one-launch loss kernel (row losses + the ticket word the last workgroup resets), one per (device, stream, batch
+# size): launches on one stream are ordered, so a workspace never serves two launches at once; the reference drives this from a
+# single Python thread on one stream (SURVEY §8(b) "Threading / streams").  Inside a stream capture the stateless two-launch form is
+# used instead (same bits: a captured graph must not share a ticket word with eager launches).
+_LOSS_WS = {}
+
+
+def _loss_workspace(score_s):
+    if not score_s.is_cuda or torch.cuda.is_current_stream_capturing():
+        return None
+    dev = score_s.device
+    key = (dev.index, ops.L.current_stream_handle(dev), int(score_s.shape[0]))
+    ws = _LOSS_WS.get(key)
+    if ws is None:
+        if len(_LOSS_WS) > 16:
+            _LOSS_WS.clear()
+        ws = _LOSS_WS[key] = ops.infonce_workspace(score_s.shape[0], dev)
+    return ws
+
+
 class _InfoNCEDistill(torch.autograd.Function):
     @staticmethod
     def forward(ctx, score_s, score_t, temperature):
-        loss, grad = ops.infonce_distill(score_s, score_t, temperature, want_grad=ctx.needs_input_grad[0])
+        loss, grad = ops.infonce_distill(score_s, score_t, temperature, want_grad=ctx.needs_input_grad[0],
+                                         ws=_loss_workspace(score_s) if score_s.dim() == 2 and score_s.shape[0] > 0 else None)
         if grad is not None:
             ctx.save_for_backward(grad)
             ctx.in_dtype = score_s.dtype

@@ -66,7 +66,8 @@ int check_common(int64_t nq, int64_t lq, int64_t np, int64_t lp) {
 int run_fwd(const uint16_t* Qp, int64_t q_stride, int64_t q_plane_stride, const uint16_t* Pp, int64_t p_stride,
             int64_t p_plane_stride, const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
             float* out, int64_t out_stride, uint16_t* argmax, int64_t nq, int64_t lq, int64_t np, int64_t lp,
-            int nplanes, const uint32_t* q_amax, const uint32_t* p_amax, int32_t* qlist_ws, hipStream_t stream) {
+            int nplanes, const uint32_t* q_amax, const uint32_t* p_amax, int32_t* qlist_ws, hipStream_t stream,
+            const int32_t* qsel = nullptr, const int32_t* qsel_count = nullptr) {
     const bool pack = (lq == 1 && nq > 1 && q_stride == EVDR_D);
     for (int64_t tok0 = 0; tok0 < lq; tok0 += 32) {
         EvdrFwdParams p{};
@@ -98,6 +99,10 @@ int run_fwd(const uint16_t* Qp, int64_t q_stride, int64_t q_plane_stride, const 
             if (eq != hipSuccess) return hip_fail(eq, "build_qlist launch");
             p.qlist = qlist_ws + 1;
             p.qcount = qlist_ws;
+        }
+        if (qsel != nullptr) {                          // evdr_maxsim_fwd_prepared_subset: one slice, the caller's device-side list
+            p.qlist = qsel;
+            p.qcount = qsel_count;
         }
         hipError_t e = evdr_launch_maxsim_fwd(p, nplanes, argmax != nullptr, stream);
         if (e != hipSuccess) return hip_fail(e, "maxsim_fwd launch");
@@ -216,6 +221,74 @@ int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes, c
     return run_fwd(Qplanes, lq * EVDR_D, nq * lq * EVDR_D, Pplanes, p_stride, p_plane_stride, qmask, tilemask, pageflags, out,
                    out_stride, argmax_or_null, nq, lq, np, lp, nplanes, nplanes == 2 ? q_amax_or_null : nullptr,
                    nplanes == 2 ? p_amax_or_null : nullptr, lq > 32 ? qlist_ws_or_null : nullptr, (hipStream_t)hip_stream);
+}
+
+int evdr_maxsim_fwd_prepared_subset(const uint16_t* Qplanes, const uint16_t* Pplanes, const uint8_t* qmask,
+                                    const uint32_t* tilemask, const uint32_t* pageflags, float* out, int64_t out_stride,
+                                    int64_t nq, int64_t lq, int64_t np, int64_t lp, int nplanes, int64_t p_stride,
+                                    int64_t p_plane_stride, const uint32_t* q_amax_or_null, const uint32_t* p_amax_or_null,
+                                    const int32_t* qsel, const int32_t* qsel_count, void* hip_stream) {
+    if (int rc = check_common(nq, lq, np, lp)) return rc;
+    if (nplanes != 1 && nplanes != 2) return fail(EVDR_ERR_ARG, "nplanes must be 1 (bf16) or 2 (fp16 hi/lo)");
+    if (nq == 0 || np == 0) return EVDR_OK;
+    if (lq == 0 || lp == 0) return fail(EVDR_ERR_SHAPE, "zero-length token axis");
+    if (lq > 32 || (lq == 1 && nq > 1)) return fail(EVDR_ERR_SHAPE, "evdr_maxsim_fwd_prepared_subset: lq must be 2..32 (or one single-token query)");
+    if (!Qplanes || !Pplanes || !tilemask || !pageflags || !out || !qsel || !qsel_count)
+        return fail(EVDR_ERR_ARG, "evdr_maxsim_fwd_prepared_subset: null pointer");
+    if (out_stride < np || p_stride < lp * EVDR_D) return fail(EVDR_ERR_ARG, "stride smaller than the row it spans");
+    return run_fwd(Qplanes, lq * EVDR_D, nq * lq * EVDR_D, Pplanes, p_stride, p_plane_stride, qmask, tilemask, pageflags, out,
+                   out_stride, nullptr, nq, lq, np, lp, nplanes, nplanes == 2 ? q_amax_or_null : nullptr,
+                   nplanes == 2 ? p_amax_or_null : nullptr, nullptr, (hipStream_t)hip_stream, qsel, qsel_count);
+}
+
+static int check_qcache(const EvdrQCache* c, const char* who) {
+    if (!c) return fail(EVDR_ERR_ARG, "%s: null cache", who);
+    if (!c->slots || !c->ent_hash || !c->ent_k || !c->ent_q || !c->ent_mask || !c->ent_scores || !c->n_entries)
+        return fail(EVDR_ERR_ARG, "%s: null pointer in the cache struct", who);
+    if (c->capacity < 1 || c->capacity > INT32_MAX - 2 || c->lq < 1 || c->np < 1 || c->row_bytes < 4 || (c->row_bytes & 3))
+        return fail(EVDR_ERR_ARG, "%s: bad cache geometry", who);
+    if (c->n_slots < 2 * c->capacity || (c->n_slots & (c->n_slots - 1)) || c->n_slots > INT32_MAX)
+        return fail(EVDR_ERR_ARG, "%s: n_slots must be a power of two >= 2 * capacity", who);
+    return EVDR_OK;
+}
+
+size_t evdr_qcache_workspace(int64_t nq) {
+    if (nq < 0) return 0;
+    return align_up((size_t)nq * 8) + 2 * align_up((size_t)nq * 4) + 256;      // hashes | hit | qsel | {miss count, ticket}
+}
+
+int evdr_maxsim_fwd_prepared_cached(const EvdrQCache* cache, const void* Qrows, const uint16_t* Qplanes, const uint16_t* Pplanes,
+                                    const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags, float* out,
+                                    int64_t out_stride, int64_t nq, int64_t lp, int nplanes, int64_t p_stride, int64_t p_plane_stride,
+                                    const uint32_t* q_amax_or_null, const uint32_t* p_amax_or_null, void* workspace,
+                                    size_t workspace_bytes, void* hip_stream) {
+    if (int rc = check_qcache(cache, "evdr_maxsim_fwd_prepared_cached")) return rc;
+    const int64_t lq = cache->lq, np = cache->np;
+    if (int rc = check_common(nq, lq, np, lp)) return rc;
+    if (nplanes != 1 && nplanes != 2) return fail(EVDR_ERR_ARG, "nplanes must be 1 (bf16) or 2 (fp16 hi/lo)");
+    if (nq == 0) return EVDR_OK;
+    if (lp == 0) return fail(EVDR_ERR_SHAPE, "zero-length token axis");
+    if (lq > 32 || lq < 2) return fail(EVDR_ERR_SHAPE, "evdr_maxsim_fwd_prepared_cached: the cache's lq must be 2..32");
+    if (!Qrows || !Qplanes || !Pplanes || !tilemask || !pageflags || !out) return fail(EVDR_ERR_ARG, "evdr_maxsim_fwd_prepared_cached: null pointer");
+    if (out_stride < np || p_stride < lp * EVDR_D) return fail(EVDR_ERR_ARG, "stride smaller than the row it spans");
+    if (!workspace || workspace_bytes < evdr_qcache_workspace(nq))
+        return fail(EVDR_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", evdr_qcache_workspace(nq), workspace_bytes);
+    hipStream_t stream = (hipStream_t)hip_stream;
+    char* ws = (char*)workspace;
+    uint64_t* hashes = (uint64_t*)ws;
+    int32_t* hit = (int32_t*)(ws + align_up((size_t)nq * 8));
+    int32_t* qsel = (int32_t*)(ws + align_up((size_t)nq * 8) + align_up((size_t)nq * 4));
+    int32_t* count = (int32_t*)(ws + align_up((size_t)nq * 8) + 2 * align_up((size_t)nq * 4));
+    uint32_t* ticket = (uint32_t*)(count + 1);
+    const uint32_t* qa = nplanes == 2 ? q_amax_or_null : nullptr;
+    hipError_t e = evdr_launch_qcache_lookup_plan(*cache, Qrows, qmask, qa, nq, hashes, hit, qsel, count, ticket, stream);
+    if (e != hipSuccess) return hip_fail(e, "qcache_lookup_plan launch");
+    if (int rc = run_fwd(Qplanes, lq * EVDR_D, nq * lq * EVDR_D, Pplanes, p_stride, p_plane_stride, qmask, tilemask, pageflags, out,
+                         out_stride, nullptr, nq, lq, np, lp, nplanes, qa, nplanes == 2 ? p_amax_or_null : nullptr, nullptr, stream,
+                         qsel, count))
+        return rc;
+    e = evdr_launch_qcache_exchange(*cache, Qrows, qmask, nq, hit, out, out_stride, stream);
+    return e == hipSuccess ? EVDR_OK : hip_fail(e, "qcache_exchange launch");
 }
 
 int evdr_maxsim_bwd(const float* g, const float* Q, const uint8_t* qmask, const uint8_t* pmask, const uint16_t* argmax,

@@ -7,7 +7,7 @@
 
 #include "../../include/evdr.h"
 
-#define EVDR_VERSION_NUM 302   /* 0.3.2: evdr_adamw_step, AdamW hyper-parameters as doubles (0.3.1: evdr_maxsim_bwd_adamw_planes; 0.3.0: debug hooks instead of environment switches) */
+#define EVDR_VERSION_NUM 303   /* 0.3.3: evdr_maxsim_fwd_prepared_subset + evdr_qcache_* (0.3.2: evdr_adamw_step, AdamW hyper-parameters as doubles; 0.3.1: evdr_maxsim_bwd_adamw_planes; 0.3.0: debug hooks instead of environment switches) */
 
 #define EVDR_D 128              /* embedding width the kernels are specialised for */
 #define EVDR_TILE_PATCHES 32    /* patches per LDS tile (two 16-row MFMA halves) */
@@ -141,6 +141,11 @@ hipError_t evdr_launch_topk(const float* scores, const int32_t* idx_map, int64_t
                             int64_t row_stride, int32_t idx_base, int k, float* top_scores, int32_t* top_idx,
                             void* workspace, hipStream_t stream);
 int evdr_topk_segments(int64_t nq, int64_t n);
+hipError_t evdr_launch_qcache_lookup_plan(const EvdrQCache& c, const void* Q, const uint8_t* qmask, const uint32_t* q_amax, int64_t nq,
+                                          uint64_t* hashes, int32_t* hit, int32_t* qsel, int32_t* qsel_count, uint32_t* ticket,
+                                          hipStream_t stream);
+hipError_t evdr_launch_qcache_exchange(const EvdrQCache& c, const void* Q, const uint8_t* qmask, int64_t nq, const int32_t* hit,
+                                       float* out, int64_t out_stride, hipStream_t stream);
 hipError_t evdr_launch_infonce(const float* ss, const float* st, int64_t b, int64_t n, float temperature,
                                float* loss, float* dscore, float* row_loss, hipStream_t stream);
 hipError_t evdr_launch_infonce_ws(const float* ss, const float* st, int64_t b, int64_t n, float temperature, float* loss,

@@ -86,6 +86,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) maxsim_fwd16_kernel(const EvdrF
     const BlockWork bw = block_work(p);
     if (!bw.valid) return;
     const int qg = bw.qg, pg0 = bw.pg0, npages = bw.npages;
+    // a launch over a device-side query list (later token slices, evdr_maxsim_fwd_prepared_subset): a workgroup whose queries all lie
+    // beyond the list has nothing to score and nothing to fetch (workgroup-uniform: before any barrier)
+    if (p.qlist != nullptr && qg * WAVES * QW >= __builtin_amdgcn_readfirstlane(*p.qcount)) return;
     const int total_tiles = npages * p.ntiles;
     const int nstages = (total_tiles + ST - 1) / ST;
 
@@ -383,6 +386,9 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     const BlockWork bw = block_work(p);
     if (!bw.valid) return;
     const int qg = bw.qg, pg0 = bw.pg0, npages = bw.npages;
+    // a launch over a device-side query list (later token slices, evdr_maxsim_fwd_prepared_subset): a workgroup whose queries all lie
+    // beyond the list has nothing to score and nothing to fetch (workgroup-uniform: before any barrier)
+    if (p.qlist != nullptr && qg * WAVES * QW >= __builtin_amdgcn_readfirstlane(*p.qcount)) return;
     // ... so that a page of k*ST + 1 tiles (1030 patches = 4*8 + 1) is k stages, the last one carrying the tail tile,
     // instead of k + 1 stages with a whole barrier / refill round for one 6-patch tile
     const bool ext = (p.ntiles % ST == 1) && (p.ntiles > ST);

@@ -25,7 +25,7 @@ from .. import ops
 from . import metrics as _metrics
 
 __all__ = ["get_torch_device", "left_padding", "BaseVisualRetrieverProcessor", "score_multi_vector_masked",
-           "CustomRetrievalEvaluator", "forget_prepared"]
+           "CustomRetrievalEvaluator", "forget_prepared", "enable_score_cache", "disable_score_cache", "score_cache_stats"]
 
 
 def get_torch_device(device: str = "auto") -> str:
@@ -50,9 +50,76 @@ def forget_prepared() -> None:
     _PREPARED.clear()
     _QPLANES.clear()
     ops._DERIVED.clear()
+    _SCORE_CACHES.clear()
+
+
+# ---- opt-in score-row cache for FROZEN pages (the reference's per-step teacher re-scoring, mainv2_iter_distill_infonce.py:282-283) ----
+# `enable_score_cache()` once -- in the re-export shim of INTEGRATION.md §1 -- and every `score_multi_vector_masked(Q, P_frozen, ...)`
+# that needs no gradient keeps, per frozen page tensor, the score row of every query row it has seen (ops.ScoreRowCache: keyed on the
+# row's bits + mask row + plane shift, verified by a full-row comparison, entirely on the device, no host synchronisation).  The
+# unmodified reference scripts then pay the frozen teacher's forward once per query instead of once per step.  The caches hang on the
+# SAME key as the prepared pages (tensor identity, layout, autograd version of P and pmask): an in-place write to P makes a new key --
+# a miss --, a dead tensor frees its cache, inference tensors (no version counter) are never cached.  Memory: `max_bytes` bounds the
+# sum over all live caches (least recently used caches are dropped first); a full cache stops storing, it never evicts rows.
+_SCORE_CACHE_BUDGET = 0                # 0 = off (the default): bytes over all live caches
+_SCORE_CACHES: "collections.OrderedDict" = collections.OrderedDict()      # prepared-pages key -> ops.ScoreRowCache | None (None: geometry refused)
+_SCORE_CACHE_HASH_MASK = 0xFFFFFFFFFFFFFFFF                                # tests narrow it to force hash collisions
+
+
+def enable_score_cache(max_bytes: int = 1 << 30) -> None:
+    """Switch the frozen-page score-row cache on (see above); `max_bytes` = device memory all caches together may hold."""
+    global _SCORE_CACHE_BUDGET
+    if max_bytes <= 0:
+        raise ValueError("enable_score_cache: max_bytes must be positive")
+    _SCORE_CACHE_BUDGET = int(max_bytes)
+
+
+def disable_score_cache() -> None:
+    global _SCORE_CACHE_BUDGET
+    _SCORE_CACHE_BUDGET = 0
+    _SCORE_CACHES.clear()
+
+
+def score_cache_stats(sync: bool = True) -> dict:
+    """{"caches", "bytes", "entries", "capacity"} over the live caches (`entries` reads device counters: one synchronising copy)."""
+    live = [c for c in _SCORE_CACHES.values() if c is not None]
+    return {"caches": len(live), "bytes": sum(c.nbytes for c in live), "capacity": sum(c.capacity for c in live),
+            "entries": sum(int(c.n_entries.item()) for c in live) if sync else None, "budget": _SCORE_CACHE_BUDGET}
+
+
+def _score_cache_for(key, P: torch.Tensor, Q: torch.Tensor):
+    """The cache of the prepared-pages entry `key` for batches shaped like Q, or None (off, not cacheable, geometry refused)."""
+    if _SCORE_CACHE_BUDGET <= 0 or key not in _PREPARED:
+        return None
+    lq = int(Q.shape[1])
+    if not (2 <= lq <= 32):                              # single-token packs and 32-token slices of long queries take the plain path
+        return None
+    hit = _SCORE_CACHES.get(key)
+    if hit is not None or key in _SCORE_CACHES:
+        if hit is not None and not hit.accepts(Q, int(P.shape[0])):
+            return None                                  # another query geometry than the one this cache was made for: scored plainly
+        if hit is not None:
+            _SCORE_CACHES.move_to_end(key)
+        return hit
+    for k in [k for k in _SCORE_CACHES if k not in _PREPARED]:          # caches of tensors that died / changed
+        del _SCORE_CACHES[k]
+    # the budget is shared: a new frozen tensor takes what the live caches leave, dropping least recently used caches if that is nothing
+    used = lambda: sum(c.nbytes for c in _SCORE_CACHES.values() if c is not None)
+    while _SCORE_CACHES and _SCORE_CACHE_BUDGET - used() < (_SCORE_CACHE_BUDGET >> 2):
+        _SCORE_CACHES.popitem(last=False)
+    try:
+        cache = ops.ScoreRowCache(lq, Q.dtype, int(P.shape[0]), _SCORE_CACHE_BUDGET - used(), Q.device, _SCORE_CACHE_HASH_MASK)
+    except ValueError:
+        cache = None                                     # the budget holds not even one row of this geometry
+    _SCORE_CACHES[key] = cache
+    return cache
 
 
 _tensor_key = ops.tensor_key           # None for None AND for inference tensors (no version counter: never cached)
+
+
+def _prepared_key(P: torch.Tensor, pmask: Optional[torch.Tensor]):
+    return (_tensor_key(P), _tensor_key(pmask))
 
 
 def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
@@ -60,7 +127,7 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
     P is the CALLER's tensor (the cache is keyed on it and dies with it); embeddings narrower than 128 are padded here, on
     a miss only -- keyed on a padded temporary, every call would redo pad + split + mask packing + the non-finite scan and push a
     live entry out of the small LRU."""
-    key = (_tensor_key(P), _tensor_key(pmask))
+    key = _prepared_key(P, pmask)
     cacheable = key[0] is not None and (pmask is None or key[1] is not None)       # not under torch.inference_mode()
     hit = _PREPARED.get(key) if cacheable else None
     if hit is not None and hit[0]() is not None and (pmask is None or hit[1]() is not None):
@@ -78,7 +145,7 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
     prep = (planes, amax, tilemask, pageflags)
     nbytes = 0 if (Pw is P and P.dtype == torch.bfloat16 and P.is_contiguous()) else planes.numel() * planes.element_size()
     if cacheable and nbytes <= _PREPARED_MAX_BYTES:
-        drop = lambda _ref, key=key: _PREPARED.pop(key, None)          # the tensor died: free its planes right away
+        drop = lambda _ref, key=key: (_PREPARED.pop(key, None), _SCORE_CACHES.pop(key, None))   # the tensor died: free its planes (and score rows) right away
         _PREPARED[key] = (weakref.ref(P, drop), weakref.ref(pmask, drop) if pmask is not None else None, prep, nbytes)
         while len(_PREPARED) > _PREPARED_MAX or sum(e[3] for e in _PREPARED.values()) > _PREPARED_MAX_BYTES:
             _PREPARED.popitem(last=False)
@@ -105,40 +172,54 @@ def _query_planes(Q: torch.Tensor):
 # ------------------------------------------------------------------------------------------------
 # A1 + A6: masked MaxSim, differentiable w.r.t. the page embeddings
 # ------------------------------------------------------------------------------------------------
+def _maxsim_forward(Q, P, qmask, pmask, need_dq: bool, need_dp: bool):
+    """The forward of A1 on whatever operands the call brings (frozen pages: prepared once per tensor and, with the score-row cache
+    on, scored once per query row; trainable pages that came out of this package's l2_normalize: their planes ride along).
+    -> (out, argmax or None, Q and P as the kernels took them: what a backward needs)."""
+    P_caller = P                                      # what the prepared-pages cache is keyed on
+    if Q.dim() == 3 and P.dim() == 3 and Q.shape[-1] == P.shape[-1] and 0 < Q.shape[-1] < ops.D:
+        Q, P = ops.pad_width(Q), ops.pad_width(P)     # narrower embeddings ride on zero columns (exact); gradients are cut back
+    both_bf16 = P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16
+    frozen = (not need_dp and P.is_cuda and P.dim() == 3 and Q.dim() == 3 and P.shape[-1] == ops.D and Q.shape[-1] == ops.D
+              and (both_bf16 or P.dtype != torch.bfloat16) and not (both_bf16 and need_dq)
+              and P.shape[0] > 0 and P.shape[1] > 0
+              and Q.shape[0] > 0 and Q.shape[1] > 0 and P.shape[1] <= 65535 and Q.shape[1] <= 65535)
+    if frozen:
+        # frozen pages: mask packing, the non-finite scan and (fp32) the plane split are done once per tensor
+        planes, amax, tilemask, pageflags = _prepared_pages(P_caller, pmask)
+        qplanes, qamax = (Q.contiguous()[None], None) if both_bf16 else _query_planes(Q)
+        cache = None
+        if _SCORE_CACHE_BUDGET > 0 and not need_dq and Q.is_contiguous() and Q.dtype in (torch.float32, torch.bfloat16):
+            cache = _score_cache_for(_prepared_key(P_caller, pmask), P, Q)
+        if cache is not None:
+            out, arg = ops.maxsim_forward_cached(cache, Q, qplanes, qamax, planes, amax, qmask, tilemask, pageflags), None
+        else:
+            out, arg = ops.maxsim_forward_prepared(qplanes, qamax, planes, amax, qmask, tilemask, pageflags,
+                                                   want_argmax=need_dq)
+    else:
+        # trainable pages that came out of this package's l2_normalize (the reference's Psb, :279) bring their planes along
+        derived = None
+        if (P_caller is P and P.is_cuda and P.dtype == torch.float32 and Q.dtype == torch.float32 and P.dim() == 3 and Q.dim() == 3
+                and P.shape[-1] == ops.D and Q.shape[-1] == ops.D and P.shape[0] > 0 and 0 < P.shape[1] <= 65535
+                and Q.shape[0] > 0 and 0 < Q.shape[1] <= 65535):
+            derived = ops.planes_of(P)
+        if derived is not None:
+            planes, amax = derived
+            tilemask, pageflags = ops.pack_pmask(pmask, P.shape[0], P.shape[1], P.device)
+            ops.flag_nonfinite(planes[0], pmask, pageflags)
+            qplanes, qamax = _query_planes(Q)
+            out, arg = ops.maxsim_forward_prepared(qplanes, qamax, planes, amax, qmask, tilemask, pageflags, want_argmax=True)
+        else:
+            out, arg = ops.maxsim_forward(Q, P, qmask, pmask, want_argmax=need_dp or need_dq)
+    return out, arg, Q, P
+
+
 class _MaxSimMasked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Q, P, qmask, pmask):
         need_dq, need_dp = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         ctx.width = int(Q.shape[-1]) if Q.dim() == 3 else ops.D
-        P_caller = P                                      # what the prepared-pages cache is keyed on
-        if Q.dim() == 3 and P.dim() == 3 and Q.shape[-1] == P.shape[-1] and 0 < Q.shape[-1] < ops.D:
-            Q, P = ops.pad_width(Q), ops.pad_width(P)     # narrower embeddings ride on zero columns (exact); gradients are cut back
-        both_bf16 = P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16
-        frozen = (not need_dp and P.is_cuda and P.dim() == 3 and Q.dim() == 3 and P.shape[-1] == ops.D and Q.shape[-1] == ops.D
-                  and (both_bf16 or P.dtype != torch.bfloat16) and not (both_bf16 and need_dq)
-                  and P.shape[0] > 0 and P.shape[1] > 0
-                  and Q.shape[0] > 0 and Q.shape[1] > 0 and P.shape[1] <= 65535 and Q.shape[1] <= 65535)
-        if frozen:
-            # frozen pages: mask packing, the non-finite scan and (fp32) the plane split are done once per tensor
-            planes, amax, tilemask, pageflags = _prepared_pages(P_caller, pmask)
-            qplanes, qamax = (Q.contiguous()[None], None) if both_bf16 else _query_planes(Q)
-            out, arg = ops.maxsim_forward_prepared(qplanes, qamax, planes, amax, qmask, tilemask, pageflags,
-                                                   want_argmax=need_dq)
-        else:
-            # trainable pages that came out of this package's l2_normalize (the reference's Psb, :279) bring their planes along
-            derived = None
-            if (P_caller is P and P.is_cuda and P.dtype == torch.float32 and Q.dtype == torch.float32 and P.dim() == 3 and Q.dim() == 3
-                    and P.shape[-1] == ops.D and Q.shape[-1] == ops.D and P.shape[0] > 0 and 0 < P.shape[1] <= 65535
-                    and Q.shape[0] > 0 and 0 < Q.shape[1] <= 65535):
-                derived = ops.planes_of(P)
-            if derived is not None:
-                planes, amax = derived
-                tilemask, pageflags = ops.pack_pmask(pmask, P.shape[0], P.shape[1], P.device)
-                ops.flag_nonfinite(planes[0], pmask, pageflags)
-                qplanes, qamax = _query_planes(Q)
-                out, arg = ops.maxsim_forward_prepared(qplanes, qamax, planes, amax, qmask, tilemask, pageflags, want_argmax=True)
-            else:
-                out, arg = ops.maxsim_forward(Q, P, qmask, pmask, want_argmax=need_dp or need_dq)
+        out, arg, Q, P = _maxsim_forward(Q, P, qmask, pmask, need_dq, need_dp)
         if need_dp or need_dq:
             ctx.save_for_backward(Q.detach(), P.detach() if need_dq else None, qmask, pmask, arg)
             ctx.p_shape, ctx.p_dtype, ctx.q_dtype = tuple(P.shape), P.dtype, Q.dtype
@@ -167,6 +248,10 @@ def score_multi_vector_masked(
     on the inputs' device, autograd-capable w.r.t. P and Q.  `chunk_p` only bounded the reference's 4-D
     intermediate (evaluator/retrieval.py:187); the fused kernel has none, so it is accepted and ignored."""
     del chunk_p
+    if not (torch.is_grad_enabled() and (Q.requires_grad or P.requires_grad)):
+        # nothing to differentiate (the reference's teacher call under torch.no_grad(), :282-283; evaluation): the same forward without
+        # the autograd.Function round trip (~10 us of host time per call, and the step is host-bound once the teacher's rows are cached)
+        return _maxsim_forward(Q, P, qmask, pmask, False, False)[0]
     return _MaxSimMasked.apply(Q, P, qmask, pmask)
 
 

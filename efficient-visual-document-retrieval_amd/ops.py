@@ -213,6 +213,78 @@ def maxsim_forward_prepared(qplanes: torch.Tensor, qamax: Optional[torch.Tensor]
     return view, arg
 
 
+class ScoreRowCache:
+    """Device-side (query row -> score row) cache of ONE prepared, frozen page tensor (include/evdr.h "score-row cache";
+    evaluator/retrieval.py builds it for the reference's per-step re-scoring of the frozen teacher,
+    mainv2_iter_distill_infonce.py:282-283).  Fixed geometry -- `lq` tokens per query, `row_dtype` rows, `npg` pages -- and a fixed
+    `capacity` chosen from a byte budget; nothing is evicted, a full cache simply stops storing.  `nbytes` = device memory held."""
+
+    def __init__(self, lq: int, row_dtype: torch.dtype, npg: int, max_bytes: int, dev, hash_mask: int = 0xFFFFFFFFFFFFFFFF):
+        self.lq, self.row_dtype, self.npg, self.dev = int(lq), row_dtype, int(npg), dev
+        self.row_bytes = self.lq * D * torch.empty((), dtype=row_dtype).element_size()
+        per_entry = self.row_bytes + self.lq + 4 * self.npg + 8 + 4 + 4 * 4        # row, mask, scores, hash, k, four table slots
+        self.capacity = int(min(max(int(max_bytes) // per_entry, 0), (1 << 30)))
+        if self.capacity < 1:
+            raise ValueError(f"score-row cache: a budget of {max_bytes} bytes holds no entry of {per_entry} bytes")
+        n_slots = 4
+        while n_slots < 2 * self.capacity:                # [2, 4) slots per entry: load factor <= 0.5, <= 16 bytes of table per entry
+            n_slots *= 2
+        self.slots = torch.zeros((n_slots,), dtype=torch.int32, device=dev)
+        self.ent_hash = torch.empty((self.capacity,), dtype=torch.int64, device=dev)
+        self.ent_k = torch.empty((self.capacity,), dtype=torch.int32, device=dev)
+        self.ent_q = torch.empty((self.capacity, self.row_bytes), dtype=torch.uint8, device=dev)
+        self.ent_mask = torch.empty((self.capacity, self.lq), dtype=torch.uint8, device=dev)
+        self.ent_scores = torch.empty((self.capacity, self.npg), dtype=torch.float32, device=dev)
+        self.n_entries = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.count = torch.zeros((1,), dtype=torch.int32, device=dev)              # view of the last call's miss count (its workspace word)
+        self._scratch = {}
+        self.c = L.EvdrQCache(self.slots.data_ptr(), n_slots, self.ent_hash.data_ptr(), self.ent_k.data_ptr(), self.ent_q.data_ptr(),
+                              self.ent_mask.data_ptr(), self.ent_scores.data_ptr(), self.n_entries.data_ptr(), self.capacity,
+                              self.row_bytes, self.lq, self.npg, hash_mask)
+        self.nbytes = sum(t.numel() * t.element_size() for t in (self.slots, self.ent_hash, self.ent_k, self.ent_q, self.ent_mask, self.ent_scores))
+
+    def scratch(self, nq: int):
+        """(workspace, miss-count view) for batches of nq queries: zeroed once, then owned by the library's ticket protocol."""
+        s = self._scratch.get(nq)
+        if s is None:
+            if len(self._scratch) > 8:
+                self._scratch.clear()
+            nbytes = int(L.load().evdr_qcache_workspace(nq))
+            ws = torch.zeros((nbytes,), dtype=torch.uint8, device=self.dev)
+            s = self._scratch[nq] = (ws, ws[nbytes - 256:nbytes - 252].view(torch.int32))
+        return s
+
+    def accepts(self, Q: torch.Tensor, npg: int) -> bool:
+        return (Q.dim() == 3 and Q.shape[1] == self.lq and Q.shape[2] == D and Q.dtype == self.row_dtype and npg == self.npg
+                and Q.device == self.dev and 2 <= self.lq <= 32)
+
+
+def maxsim_forward_cached(cache: ScoreRowCache, Q: torch.Tensor, qplanes: torch.Tensor, qamax: Optional[torch.Tensor], pplanes: torch.Tensor,
+                          pamax: Optional[torch.Tensor], qmask: Optional[torch.Tensor], tilemask: torch.Tensor,
+                          pageflags: torch.Tensor) -> torch.Tensor:
+    """A1 on prepared operands THROUGH the score-row cache (evdr_maxsim_fwd_prepared_cached): lookup + plan -> forward over the
+    missing queries only -> exchange, three launches on the current stream behind ONE C call and no host synchronisation (which queries were missing is decided and consumed on the
+    device).  Q is the caller's dense (nq, lq, 128) batch -- its bits are the key --, qplanes / qamax its planes as the forward
+    takes them.  The result is, bit for bit, what `maxsim_forward_prepared` returns for the same call."""
+    dev = _require_cuda(Q, qplanes, pplanes)
+    nq, lq, _ = Q.shape
+    nplanes, npg, lp, _ = pplanes.shape
+    if not cache.accepts(Q, npg) or not Q.is_contiguous():
+        raise RuntimeError("maxsim_forward_cached: the batch does not match the cache's geometry")
+    out = torch.empty((nq, npg), dtype=torch.float32, device=dev)
+    if nq == 0:
+        return out
+    qm = _mask_u8(qmask, (nq, lq), dev)
+    ws, cache.count = cache.scratch(nq)
+    lib = L.load()
+    with L.on(dev):
+        L.check(lib.evdr_maxsim_fwd_prepared_cached(
+            L.C.byref(cache.c), L.ptr(Q), L.ptr(qplanes), L.ptr(pplanes), L.ptr(qm), L.ptr(tilemask), L.ptr(pageflags), L.ptr(out),
+            out.stride(0), nq, lp, nplanes, int(pplanes.stride(1)), int(pplanes.stride(0)), L.ptr(qamax), L.ptr(pamax), L.ptr(ws),
+            ws.numel(), L.current_stream_handle(dev)))
+    return out
+
+
 def maxsim_backward(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torch.Tensor], pmask: Optional[torch.Tensor],
                     argmax: torch.Tensor, npg: int, lp: int) -> torch.Tensor:
     """A6: dP (np, lp, 128) fp32 from upstream g (nq, np) and the forward's argmax."""

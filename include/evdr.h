@@ -148,6 +148,58 @@ EVDR_API int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* P
                              const uint32_t* q_amax_or_null, const uint32_t* p_amax_or_null,
                              int32_t* qlist_ws_or_null, void* hip_stream);
 
+/* The same forward for a device-side SUBSET of the queries: only the queries qsel[0 .. *qsel_count) (ascending indices into the
+ * nq rows of Qplanes, both in device memory) are scored and only their rows of `out` are written; workgroups whose queries all lie
+ * beyond *qsel_count leave at once.  The count is read on the device: the host needs no synchronisation to know which queries a
+ * preceding kernel selected (the score-row cache below).  lq <= 32 and lq != 1-packed layouts only (EVDR_ERR_SHAPE otherwise); no argmax. */
+EVDR_API int evdr_maxsim_fwd_prepared_subset(const uint16_t* Qplanes, const uint16_t* Pplanes,
+                             const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
+                             float* out, int64_t out_stride,
+                             int64_t nq, int64_t lq, int64_t np, int64_t lp,
+                             int nplanes, int64_t p_stride, int64_t p_plane_stride,
+                             const uint32_t* q_amax_or_null, const uint32_t* p_amax_or_null,
+                             const int32_t* qsel, const int32_t* qsel_count, void* hip_stream);
+
+/* ---- score-row cache of a FROZEN page tensor (mainv2_iter_distill_infonce.py:282-283) --------------------------------------------
+ * The reference's step re-scores the frozen teacher pages for every batch, every epoch, although a query's teacher scores never
+ * change ("caching them is a legal, result-identical optimisation").  evdr_maxsim_fwd_prepared_cached is
+ * evdr_maxsim_fwd_prepared (no argmax) through a (query row -> score row) cache that lives on the device, for ONE prepared page
+ * tensor, without any host synchronisation.  Three launches on `hip_stream`:
+ *   lookup + plan   one workgroup per query: 64-bit hash of (query row bits, mask row, plane shift k of the batch), probe of an
+ *                   open-addressing table, and -- on a hash match -- a comparison of the FULL stored row and mask, so that a hash
+ *                   collision is a miss.  The last workgroup to finish turns the misses, in ascending order, into the query list of
+ *                   the forward and, while the cache has room, gives each a fresh entry and enters it into the table;
+ *   forward         evdr_maxsim_fwd_prepared_subset over that device-side list (all hits: every workgroup leaves at once);
+ *   exchange        rows of hits are copied out of the cache into `out`, rows of stored misses (score row, query row, mask) into it.
+ * The plane shift k (evdr_split_f32 scales a batch by one power of two taken from ITS absmax) is part of the key: a query that comes
+ * back in a batch with another absmax exponent is scored again, so a cached row always equals, bit for bit, the row
+ * evdr_maxsim_fwd_prepared would write for this very call.  Nothing is evicted: a full cache keeps its entries and later misses are
+ * just scored.  One cache belongs to one stream order of calls (never two streams at once).
+ * Qrows: the batch as the caller holds it, (nq, cache->lq, 128) dense, cache->row_bytes per query (fp32 or bf16) -- its bits are the
+ * key; Qplanes / q_amax: the same batch as the forward takes it.  workspace: evdr_qcache_workspace(nq) bytes, ZEROED by the caller
+ * before its first use and then left to the library (it carries a ticket word between calls; after a call the int32 at byte offset
+ * evdr_qcache_workspace(nq) - 256 holds the number of queries that had to be scored).
+ * The struct is plain host memory; all of its pointers are device memory owned by the caller. */
+typedef struct EvdrQCache {
+    int32_t*  slots;        /* (n_slots) open-addressing table: 0 = empty, else entry index + 1; zero-initialised by the caller */
+    int64_t   n_slots;      /* a power of two, >= 2 * capacity                                                                      */
+    uint64_t* ent_hash;     /* (capacity)                                                                                         */
+    int32_t*  ent_k;        /* (capacity) plane shift the entry was scored with                                                   */
+    uint8_t*  ent_q;        /* (capacity, row_bytes) query rows as the caller's dtype holds them                                  */
+    uint8_t*  ent_mask;     /* (capacity, lq) mask rows, 0 / 1                                                                     */
+    float*    ent_scores;   /* (capacity, np)                                                                                     */
+    int32_t*  n_entries;    /* (1) entries handed out so far; zero-initialised by the caller                                      */
+    int64_t   capacity, row_bytes, lq, np;
+    uint64_t  hash_mask;    /* all ones; tests narrow it (0 = every row collides) to exercise the full-row comparison             */
+} EvdrQCache;
+EVDR_API size_t evdr_qcache_workspace(int64_t nq);
+EVDR_API int evdr_maxsim_fwd_prepared_cached(const EvdrQCache* cache, const void* Qrows, const uint16_t* Qplanes, const uint16_t* Pplanes,
+                             const uint8_t* qmask, const uint32_t* tilemask, const uint32_t* pageflags,
+                             float* out, int64_t out_stride, int64_t nq, int64_t lp,
+                             int nplanes, int64_t p_stride, int64_t p_plane_stride,
+                             const uint32_t* q_amax_or_null, const uint32_t* p_amax_or_null,
+                             void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* ---- A6: autograd of A1 w.r.t. P (loss.backward(), mainv2_iter_distill_infonce.py:290) ---------------
  * dP[p,m,:] = sum_{q,n} g[q,p] * qmask[q,n] * has(p) * [m == argmax[q,p,n]] * Q[q,n,:]
  * g (nq,np) fp32; Q (nq,lq,128) fp32; argmax from evdr_maxsim_fwd; dP (np,lp,128) fp32 is

@@ -51,7 +51,7 @@ def test_exports_equal_the_header(lib):
 
 def test_version_and_error_string(lib):
     from evdr_amd import _lib
-    assert lib.evdr_version() == _lib.ABI_VERSION == 302
+    assert lib.evdr_version() == _lib.ABI_VERSION == 303
     assert isinstance(lib.evdr_last_error(), bytes)
 
 
@@ -79,6 +79,17 @@ def test_argument_errors_need_no_gpu(lib):
     assert lib.evdr_maxsim_fwd_workspace(8, 32, 64, 1030, L.EVDR_F32) > 2 * 64 * 1030 * 128 * 2
     assert lib.evdr_maxsim_fwd_workspace(8, 32, 64, 1030, L.EVDR_BF16) < 64 * 1030 * 4
     assert lib.evdr_maxsim_topk_workspace(10, 10) >= 400
+    # round 6: the score-row cache entries and the subset forward refuse bad arguments before touching the device
+    assert lib.evdr_maxsim_fwd_prepared_cached(None, None, None, None, None, None, None, None, 8, 4, 64, 1, 64 * 128, 0, None, None, None, 0, None) == L.EVDR_ERR_ARG
+    assert b"null cache" in lib.evdr_last_error()
+    bad = L.EvdrQCache(1, 6, 1, 1, 1, 1, 1, 1, 3, 16, 2, 8, 0xFFFFFFFFFFFFFFFF)      # pointers are fake: nothing is dereferenced on the host
+    assert lib.evdr_maxsim_fwd_prepared_cached(ctypes.byref(bad), None, None, None, None, None, None, None, 8, 4, 64, 1, 64 * 128, 0, None, None, None, 0, None) == L.EVDR_ERR_ARG
+    assert b"power of two" in lib.evdr_last_error()
+    bad.n_slots = 8
+    assert lib.evdr_maxsim_fwd_prepared_cached(ctypes.byref(bad), 1, 1, 1, None, 1, 1, 1, 8, 4, 64, 1, 64 * 128, 0, None, None, None, 0, None) == L.EVDR_ERR_WORKSPACE
+    assert lib.evdr_qcache_workspace(32) >= 32 * 16 + 8 and lib.evdr_qcache_workspace(-1) == 0
+    rc = lib.evdr_maxsim_fwd_prepared_subset(None, None, None, None, None, None, 8, 4, 40, 8, 64, 1, 64 * 128, 0, None, None, None, None, None)
+    assert rc == L.EVDR_ERR_SHAPE and b"lq" in lib.evdr_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
