@@ -213,14 +213,15 @@ int evdr_maxsim_fwd_prepared(const uint16_t* Qplanes, const uint16_t* Pplanes, c
                              int64_t p_stride, int64_t p_plane_stride, const uint32_t* q_amax_or_null,
                              const uint32_t* p_amax_or_null, int32_t* qlist_ws_or_null, void* hip_stream) {
     if (int rc = check_common(nq, lq, np, lp)) return rc;
-    if (nplanes != 1 && nplanes != 2) return fail(EVDR_ERR_ARG, "nplanes must be 1 (bf16) or 2 (fp16 hi/lo)");
+    if (nplanes != 1 && nplanes != 2 && nplanes != 4)
+        return fail(EVDR_ERR_ARG, "nplanes must be 1 (bf16), 2 (fp16 hi/lo) or 4 (fp16 hi/lo x two 128-column blocks: width 256)");
     if (nq == 0 || np == 0) return EVDR_OK;
     if (lq == 0 || lp == 0) return fail(EVDR_ERR_SHAPE, "zero-length token axis");
     if (!Qplanes || !Pplanes || !tilemask || !pageflags || !out) return fail(EVDR_ERR_ARG, "evdr_maxsim_fwd_prepared: null pointer");
     if (out_stride < np || p_stride < lp * EVDR_D) return fail(EVDR_ERR_ARG, "stride smaller than the row it spans");
     return run_fwd(Qplanes, lq * EVDR_D, nq * lq * EVDR_D, Pplanes, p_stride, p_plane_stride, qmask, tilemask, pageflags, out,
-                   out_stride, argmax_or_null, nq, lq, np, lp, nplanes, nplanes == 2 ? q_amax_or_null : nullptr,
-                   nplanes == 2 ? p_amax_or_null : nullptr, lq > 32 ? qlist_ws_or_null : nullptr, (hipStream_t)hip_stream);
+                   out_stride, argmax_or_null, nq, lq, np, lp, nplanes, nplanes >= 2 ? q_amax_or_null : nullptr,
+                   nplanes >= 2 ? p_amax_or_null : nullptr, lq > 32 ? qlist_ws_or_null : nullptr, (hipStream_t)hip_stream);
 }
 
 int evdr_maxsim_fwd_prepared_subset(const uint16_t* Qplanes, const uint16_t* Pplanes, const uint8_t* qmask,

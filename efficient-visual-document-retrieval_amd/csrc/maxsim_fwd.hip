@@ -78,6 +78,8 @@ hipError_t evdr_launch_maxsim_fwd(const EvdrFwdParams& pin, int nplanes, bool wa
             qw = 8;
         }
 #endif
+    } else if (nplanes == 4) {
+        qw = 1;                             // 256-wide embeddings (two column blocks of fp16 hi/lo planes): the query fragments of ONE query fill half the register file
     } else {
         qw = (p.nq > 8) ? 2 : 1;
         // Small launches (a page shard of a multi-GPU training step: 32 queries x 63 pages = 126 workgroups of 16 queries on 256

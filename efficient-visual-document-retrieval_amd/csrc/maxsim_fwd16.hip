@@ -363,18 +363,26 @@ __device__ __forceinline__ void xgroup_argmax(float& v, int& idx) {
     }
 }
 
-template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, int WAVES = 8, bool NT = false>
+// NCB = 2 (round 6): embeddings of width 256 as TWO 128-column blocks per value plane -- the memory / LDS / register layout simply has
+//          NPL * NCB planes of (., ., 128) (plane index = value plane * NCB + column block), and a dot product is the sum of the
+//          per-block plane products into ONE accumulator chain (the max over patches needs the whole 256-wide product, so the blocks
+//          cannot be scored apart).  fp16 hi/lo planes only (bf16 inputs of that width are upcast like the reference does,
+//          evaluator/retrieval.py:176-177), one query per wave (128 VGPRs of query fragments), 1-tile stages (4 planes = 32 KiB a tile).
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, int WAVES = 8, bool NT = false, int NCB = 1>
 __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const EvdrFwdParams p) {
     using frag = typename FragOf<NPL>::type;
+    constexpr int NPLN = NPL * NCB;                       // planes of a tile in memory, in LDS and in the query fragments
+    static_assert(NCB == 1 || (NCB == 2 && NPL == 2 && QW == 1), "256-wide embeddings: fp16 hi/lo planes, one query per wave");
     static_assert(WAVES == 8 || (WAVES == 4 && !BAL), "8 waves (one workgroup per CU) or 4 (two independent workgroups per CU)");
-    constexpr int TILE_B = NPL * TILE_BYTES;              // planes of one tile are adjacent 8-KiB images
+    constexpr int TILE_B = NPLN * TILE_BYTES;             // planes of one tile are adjacent 8-KiB images
     constexpr int SLOT_TILES = ST + 1;                    // a ring slot holds one tile more than a stage's ST ...
     constexpr int STAGE_BYTES = SLOT_TILES * TILE_B;
-    constexpr int G = ST * NPL * 8 / WAVES;               // LDS-DMA pieces per wave per stage (8 pieces per tile and plane)
+    constexpr int G = ST * NPLN * 8 / WAVES;              // LDS-DMA pieces per wave per stage (8 pieces per tile and plane)
     // plane products (A = page plane, B = query plane), smaller magnitude first
-    constexpr int NPROD = (NPL == 1) ? 1 : 3;
-    constexpr int PA[3] = {NPL - 1, 0, 0};
-    constexpr int PB[3] = {0, NPL - 1, 0};
+    // per column block cb: lo_cb x hi_cb, hi_cb x lo_cb, hi_cb x hi_cb (hi = value plane 0, lo = value plane 1; plane = value * NCB + cb)
+    constexpr int NPROD = ((NPL == 1) ? 1 : 3) * NCB;
+    constexpr int PA[6] = {(NPL - 1) * NCB, 0, 0, (NPL - 1) * NCB + 1, 1, 1};
+    constexpr int PB[6] = {0, (NPL - 1) * NCB, 0, 1, (NPL - 1) * NCB + 1, 1};
     static_assert(NPL == 1 || NPL == 2, "one bf16 plane or fp16 hi/lo planes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -401,7 +409,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     int qreal[QW];                                        // wave-uniform: the queries of this wave, -1 = none
     resolve_queries<QW>(p, q0, qreal);
     bool active = qreal[0] >= 0;
-    frag bq[QW][NPL][2][4];
+    frag bq[QW][NPLN][2][4];
     float qwt[QW][2];
     // Query fragments come in THROUGH LDS (below, once the first stage is on its way): a fragment load straight from global
     // memory touches 16 rows x 64 B per instruction -- half of every 128-B line -- and the four k-steps of a row are four
@@ -477,8 +485,8 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     auto issue_piece = [&](const uint16_t* sbp, int t0, int tlo, int thi, int slot, int i, auto full_tag) {
         constexpr bool KNOWN_FULL = decltype(full_tag)::value;       // caller guarantees the stage has all ST tiles
         const int pc = wave * G + i;
-        const int tis = pc / (8 * NPL);
-        const int rem = pc - tis * (8 * NPL);
+        const int tis = pc / (8 * NPLN);
+        const int rem = pc - tis * (8 * NPLN);
         const int pl = rem >> 3, piece = rem & 7;
         if (!KNOWN_FULL && (t0 + tis >= p.ntiles || t0 + tis < tlo || t0 + tis > thi)) return;
         const int rrel = tis * EVDR_TILE_PATCHES + piece * 4;                        // piece's first row inside the stage (uniform)
@@ -502,7 +510,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             const int rbase = min(row0, p.lp - 1);
             const uint32_t voff = ((voff0 ^ ((uint32_t)(piece & 3) << 6)) & 0xFFu) + (uint32_t)(min(row0 + (lane >> 4), p.lp - 1) - rbase) * 256u;
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
+            for (int pl = 0; pl < NPLN; ++pl) {
                 const uint16_t* sb = p.P + (int64_t)pl * p.p_plane_stride + (int64_t)(pg0 + pgi) * p.p_stride + (int64_t)rbase * EVDR_D;
                 lds_dma_16B_sbase(sb, voff,
                                   __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES + ST * TILE_B + pl * TILE_BYTES + piece * 1024));
@@ -526,14 +534,14 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     int ridx[QW][2];
     const int gx = g ^ c;
     const char* a_lane = smem + c * (EVDR_D * 2);
-    auto load_half = [&](frag (&a)[NPL][4], const char* sbase, int tis, int u) {
+    auto load_half = [&](frag (&a)[NPLN][4], const char* sbase, int tis, int u) {
         const char* tb = sbase + tis * TILE_B + u * (16 * EVDR_D * 2);
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
+        for (int pl = 0; pl < NPLN; ++pl)
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) a[pl][s4] = *reinterpret_cast<const frag*>(tb + pl * TILE_BYTES + (((4 * s4) ^ gx) << 4));
     };
-    auto chain = [&](const frag (&a)[NPL][4], int j, int t) {
+    auto chain = [&](const frag (&a)[NPLN][4], int j, int t) {
         f32x4v acc = {0, 0, 0, 0};
 #pragma unroll
         for (int pr = 0; pr < NPROD; ++pr)
@@ -562,7 +570,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
         }
     };
     // pbase: first patch index of the 16-patch half (uniform); the lane's accumulator i is patch pbase + 4g + i
-    auto chains_full = [&](const frag (&a)[NPL][4], int pbase) {           // all 16 patches of the half valid
+    auto chains_full = [&](const frag (&a)[NPLN][4], int pbase) {          // all 16 patches of the half valid
         const int pb = pbase + 4 * g;
         if constexpr (NPL == 1 && (QW <= 2 || QW >= 8)) {
             // one or two queries per wave: the 2 QW chains of a half-tile are issued INTERLEAVED (k-step outermost), so that
@@ -590,7 +598,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                 for (int t = 0; t < 2; ++t) fold(chain(a, j, t), j, t, pb);
         }
     };
-    auto chains_masked = [&](const frag (&a)[NPL][4], uint32_t bits, int pbase) {
+    auto chains_masked = [&](const frag (&a)[NPLN][4], uint32_t bits, int pbase) {
         const int pb = pbase + 4 * g;
         uint32_t mybits = bits >> (4 * g);
         asm volatile("" : "+v"(mybits));
@@ -667,7 +675,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
             const int nr = max(qrows[j], 1);
             const uint16_t* qb = p.Q + (int64_t)max(qreal[j], 0) * p.q_stride + (int64_t)p.tok0 * EVDR_D;
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
+            for (int pl = 0; pl < NPLN; ++pl) {
                 if (j + pl > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the window's previous tenant has been read
 #pragma unroll
                 for (int piece = 0; piece < 8; ++piece) {
@@ -695,15 +703,17 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
         for (int t = 0; t < 2; ++t)
             if (!qok[j][t]) {
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
+                for (int pl = 0; pl < NPLN; ++pl)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) bq[j][pl][t][s] = frag{0, 0, 0, 0, 0, 0, 0, 0};
             }
 #pragma unroll
-    for (int j = 0; j < QW; ++j) {                        // plane 0 is the hi plane: NaN and Inf survive the split there
+    for (int j = 0; j < QW; ++j) {                        // the hi planes (one per column block): NaN and Inf survive the split there
         uint32_t c0 = 0u, c1 = 0u;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { c0 |= frag_exp_carry(bq[j][0][0][s]); c1 |= frag_exp_carry(bq[j][0][1][s]); }
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { c0 |= frag_exp_carry(bq[j][cb][0][s]); c1 |= frag_exp_carry(bq[j][cb][1][s]); }
         qbad[j] = token_bad_bits((c0 & 0x80008000u) != 0u, (c1 & 0x80008000u) != 0u);
     }
     if constexpr (QW >= 8) {
@@ -714,7 +724,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
 #pragma unroll
         for (int j = 0; j < QW; ++j)
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
+            for (int pl = 0; pl < NPLN; ++pl)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -856,7 +866,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                 page_span(npf, klo, khi, ntlo, nthi);
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
-                    const int t = nt0 + (wave * G + i) / (8 * NPL);
+                    const int t = nt0 + (wave * G + i) / (8 * NPLN);
                     want |= (t >= ntlo && t <= nthi && t < p.ntiles) ? (1u << i) : 0u;
                 }
             }
@@ -927,7 +937,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                 for (int u = 0; u < 2; ++u) {
                     const uint32_t bits = (tm >> (16 * u)) & 0xFFFFu;
                     if (bits == 0u) continue;
-                    frag a[NPL][4];
+                    frag a[NPLN][4];
                     load_half(a, sbase, tis, u);
                     const int pbase = tip * EVDR_TILE_PATCHES + 16 * u;
                     if (bits == 0xFFFFu) chains_full(a, pbase); else chains_masked(a, bits, pbase);
@@ -992,7 +1002,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                             // stalled on every fragment (measured with the LDS-DMA removed: 30-40 cycles per MFMA).  The small
                             // instances have the registers for a deeper ring of fragments: 4 halves ahead at QW = 1 and 2 (not with the argmax).
                             constexpr int DEPTH = (QW <= 2 && !ARGMAX) ? 4 : 2;
-                            frag a[DEPTH][NPL][4];
+                            frag a[DEPTH][NPLN][4];
 #pragma unroll
                             for (int h = 0; h < DEPTH; ++h) load_half(a[h], sbase, h >> 1, h & 1);
 #pragma unroll
@@ -1026,8 +1036,10 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
 #pragma unroll
                                 for (int s4 = 0; s4 < 4; ++s4) a[s4] = *reinterpret_cast<const frag*>(tb + (((4 * s4) ^ gx) << 4));
                             };
+                            // (NCB column blocks: the same three phases per block, into the same accumulators; page planes hi_cb = cb,
+                            // lo_cb = NCB + cb, and likewise for the query fragments)
                             frag al[4], ah[4];
-                            load_plane(al, 0, 1);
+                            load_plane(al, 0, NCB);
                             load_plane(ah, 0, 0);
 #pragma unroll
                             for (int h = 0; h < 2 * ST; ++h) {
@@ -1036,37 +1048,42 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
 #pragma unroll
                                 for (int j = 0; j < QW; ++j) acc[j][0] = acc[j][1] = f32x4v{0, 0, 0, 0};
 #pragma unroll
-                                for (int s4 = 0; s4 < 4; ++s4)
+                                for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
-                                    for (int j = 0; j < QW; ++j)
+                                    for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                                        for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(al[s4], bq[j][0][t][s4], acc[j][t]);
-                                asm volatile("" ::: "memory");
-                                fault_hold(h == 2 * ST - 3);
-                                if (h + 1 < 2 * ST) load_plane(al, h + 1, 1);
-                                if constexpr (SP) {
-                                    if ((h & 1) == 0) {
+                                        for (int j = 0; j < QW; ++j)
 #pragma unroll
-                                        for (int i = refill_lo(h >> 1); i < refill_hi(h >> 1); ++i) issue_piece(nbase, nt0, 0, 0, nslot, i, std::true_type{});
+                                            for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(al[s4], bq[j][cb][t][s4], acc[j][t]);
+                                    asm volatile("" ::: "memory");
+                                    if (cb == 0) fault_hold(h == 2 * ST - 3);
+                                    if (cb + 1 < NCB) load_plane(al, h, NCB + cb + 1);
+                                    else if (h + 1 < 2 * ST) load_plane(al, h + 1, NCB);
+                                    if constexpr (SP) {
+                                        if (cb == 0 && (h & 1) == 0) {
+#pragma unroll
+                                            for (int i = refill_lo(h >> 1); i < refill_hi(h >> 1); ++i) issue_piece(nbase, nt0, 0, 0, nslot, i, std::true_type{});
+                                        }
                                     }
+#pragma unroll
+                                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                                        for (int j = 0; j < QW; ++j)
+#pragma unroll
+                                            for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][NCB + cb][t][s4], acc[j][t]);
+#pragma unroll
+                                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                                        for (int j = 0; j < QW; ++j)
+#pragma unroll
+                                            for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][cb][t][s4], acc[j][t]);
+                                    // the next half's hi-plane fragments go into the registers the last product just released: the
+                                    // LDS reads must not be hoisted above it (the scheduler did, and paid with spills INSIDE the block,
+                                    // whose scratch reloads wait on vmcnt -- i.e. on the LDS-DMA refill in flight)
+                                    asm volatile("" ::: "memory");
+                                    if (cb + 1 < NCB) load_plane(ah, h, cb + 1);
+                                    else if (h + 1 < 2 * ST) load_plane(ah, h + 1, 0);
                                 }
-#pragma unroll
-                                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                                    for (int j = 0; j < QW; ++j)
-#pragma unroll
-                                        for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][1][t][s4], acc[j][t]);
-#pragma unroll
-                                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                                    for (int j = 0; j < QW; ++j)
-#pragma unroll
-                                        for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][0][t][s4], acc[j][t]);
-                                // the next half's hi-plane fragments go into the registers the last product just released: the
-                                // LDS reads must not be hoisted above it (the scheduler did, and paid with spills INSIDE the block,
-                                // whose scratch reloads wait on vmcnt -- i.e. on the LDS-DMA refill in flight)
-                                asm volatile("" ::: "memory");
-                                if (h + 1 < 2 * ST) load_plane(ah, h + 1, 0);
                                 const int pb = (t0 + (h >> 1)) * EVDR_TILE_PATCHES + 16 * (h & 1) + 4 * g;
 #pragma unroll
                                 for (int j = 0; j < QW; ++j)
@@ -1113,7 +1130,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                     }
                     auto full_run = [&](int tis0, int len) {
                         if constexpr (NPL == 1) {
-                            frag alo[NPL][4], ahi[NPL][4];
+                            frag alo[NPLN][4], ahi[NPLN][4];
                             load_half(alo, sbase, tis0, 0);
                             load_half(ahi, sbase, tis0, 1);
 #pragma unroll 1
@@ -1137,7 +1154,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
                                 for (int s4 = 0; s4 < 4; ++s4) a[s4] = *reinterpret_cast<const frag*>(tb + (((4 * s4) ^ gx) << 4));
                             };
                             frag al[4], ah[4];
-                            load_plane(al, 2 * tis0, 1);
+                            load_plane(al, 2 * tis0, NCB);
                             load_plane(ah, 2 * tis0, 0);
 #pragma unroll 1
                             for (int i = 0; i < len; ++i) {
@@ -1149,25 +1166,28 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
 #pragma unroll
                                     for (int j = 0; j < QW; ++j) acc[j][0] = acc[j][1] = f32x4v{0, 0, 0, 0};
 #pragma unroll
-                                    for (int s4 = 0; s4 < 4; ++s4)
+                                    for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
-                                        for (int j = 0; j < QW; ++j)
+                                        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                                            for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(al[s4], bq[j][0][t][s4], acc[j][t]);
-                                    load_plane(al, hn, 1);
+                                            for (int j = 0; j < QW; ++j)
 #pragma unroll
-                                    for (int s4 = 0; s4 < 4; ++s4)
+                                                for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(al[s4], bq[j][cb][t][s4], acc[j][t]);
+                                        if (cb + 1 < NCB) load_plane(al, h, NCB + cb + 1); else load_plane(al, hn, NCB);
 #pragma unroll
-                                        for (int j = 0; j < QW; ++j)
+                                        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                                            for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][1][t][s4], acc[j][t]);
+                                            for (int j = 0; j < QW; ++j)
 #pragma unroll
-                                    for (int s4 = 0; s4 < 4; ++s4)
+                                                for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][NCB + cb][t][s4], acc[j][t]);
 #pragma unroll
-                                        for (int j = 0; j < QW; ++j)
+                                        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                                            for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][0][t][s4], acc[j][t]);
-                                    load_plane(ah, hn, 0);
+                                            for (int j = 0; j < QW; ++j)
+#pragma unroll
+                                                for (int t = 0; t < 2; ++t) acc[j][t] = mfma16(ah[s4], bq[j][cb][t][s4], acc[j][t]);
+                                        if (cb + 1 < NCB) load_plane(ah, h, cb + 1); else load_plane(ah, hn, 0);
+                                    }
                                     const int pb = (t0 + (h >> 1)) * EVDR_TILE_PATCHES + 16 * (h & 1) + 4 * g;
 #pragma unroll
                                     for (int j = 0; j < QW; ++j)
@@ -1274,18 +1294,18 @@ __global__ void __launch_bounds__(WAVES * 64, OCC) maxsim_fwd16s_kernel(const Ev
     }
 }
 
-template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, int WAVES = 8, bool NT = false>
+template <int QW, int NPL, bool ARGMAX, int ST, int NSTAGE, bool DIAG = false, bool BAL = false, int OCC = 2, int WAVES = 8, bool NT = false, int NCB = 1>
 hipError_t launch16s(const EvdrFwdParams& pin, hipStream_t stream) {
     EvdrFwdParams p = pin;
-    constexpr int LDS = NSTAGE * (ST + 1) * NPL * TILE_BYTES;
-    auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC, WAVES, NT>;
+    constexpr int LDS = NSTAGE * (ST + 1) * NPL * NCB * TILE_BYTES;
+    auto kern = maxsim_fwd16s_kernel<QW, NPL, ARGMAX, ST, NSTAGE, DIAG, BAL, OCC, WAVES, NT, NCB>;
     static std::atomic<uint64_t> attr_devs{0};
     if (hipError_t e = evdr_ensure_dyn_lds((const void*)kern, LDS, attr_devs); e != hipSuccess) return e;
     const int64_t blocks = evdr_set_geometry(p, WAVES * QW, LDS <= 80 * 1024 ? 2 : 1);      // two workgroups share a CU's 160 KiB, or one owns it
     static const char* const name = [] {
         static char buf[96];
-        snprintf(buf, sizeof(buf), "maxsim_fwd16s_kernel<%d,%d,%s,%d,%d,%s,%s,%d,%d,%s>", QW, NPL, ARGMAX ? "true" : "false", ST, NSTAGE,
-                 DIAG ? "true" : "false", BAL ? "true" : "false", OCC, WAVES, NT ? "true" : "false");
+        snprintf(buf, sizeof(buf), "maxsim_fwd16s_kernel<%d,%d,%s,%d,%d,%s,%s,%d,%d,%s>%s", QW, NPL, ARGMAX ? "true" : "false", ST, NSTAGE,
+                 DIAG ? "true" : "false", BAL ? "true" : "false", OCC, WAVES, NT ? "true" : "false", NCB == 2 ? "x2cols" : "");
         return (const char*)buf;
     }();
     evdr_note_fwd_kernel(name);
@@ -1338,6 +1358,11 @@ hipError_t evdr_launch_maxsim_fwd16(const EvdrFwdParams& p, int qw, int waves, i
         return launch16s<2, 2, false, 4, 2, true, true>(pd, stream);
     }
 #endif
+    if (nplanes == 4) {
+        // 256-wide embeddings as fp16 hi/lo planes x two 128-column blocks (NCB = 2): one query per wave, 1-tile stages
+        return want_argmax ? launch16s<1, 2, true, 1, 2, false, true, 2, 8, false, 2>(p, stream)
+                           : launch16s<1, 2, false, 1, 2, false, true, 2, 8, false, 2>(p, stream);
+    }
     if (nplanes == 2) {
 #ifdef EVDR_EXPERIMENT
         // variant 12 (experiment build): the student forward as TWO independent 4-wave workgroups per CU (1-tile stages, 64 KiB of

@@ -134,7 +134,10 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
         _PREPARED.move_to_end(key)
         return hit[2]
     Pw = ops.pad_width(P)
-    if Pw.dtype == torch.bfloat16:                     # scored as they are: only the packed masks and the non-finite scan are kept
+    wide = Pw.shape[-1] == ops.D_WIDE                  # 129..256 columns: four planes (fp16 hi/lo x two column blocks), any input dtype
+    if wide:
+        planes, amax = ops.split_wide(Pw)
+    elif Pw.dtype == torch.bfloat16:                   # scored as they are: only the packed masks and the non-finite scan are kept
         planes, amax = Pw.contiguous()[None], None
     else:
         # pages that came out of this package's l2_normalize bring their planes along (ops.planes_of); others are split here
@@ -142,6 +145,8 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
         planes, amax = made if made is not None else ops.split_f32(Pw)
     tilemask, pageflags = ops.pack_pmask(pmask, P.shape[0], P.shape[1], P.device)
     ops.flag_nonfinite(planes[0], pmask, pageflags)
+    if wide:
+        ops.flag_nonfinite(planes[1], pmask, pageflags)               # the hi plane of the second column block
     prep = (planes, amax, tilemask, pageflags)
     nbytes = 0 if (Pw is P and P.dtype == torch.bfloat16 and P.is_contiguous()) else planes.numel() * planes.element_size()
     if cacheable and nbytes <= _PREPARED_MAX_BYTES:
@@ -159,12 +164,13 @@ def _query_planes(Q: torch.Tensor):
     """fp16 hi/lo planes of an fp32 query batch.  The reference's step scores ONE batch twice in a row -- against the teacher
     and against the student (mainv2_iter_distill_infonce.py:283,286) -- so the last batch's planes are kept while that tensor is
     alive and unwritten (key as for the prepared pages)."""
+    split = ops.split_wide if Q.shape[-1] == ops.D_WIDE else ops.split_f32
     key = _tensor_key(Q)
     if key is None:                                     # inference tensor: split per call
-        return ops.split_f32(Q)
+        return split(Q)
     if _QPLANES and _QPLANES[0][1] == key and _QPLANES[0][0]() is not None:
         return _QPLANES[0][2]
-    made = ops.split_f32(Q)
+    made = split(Q)
     _QPLANES[:] = [(weakref.ref(Q, lambda _r: _QPLANES.clear() if (_QPLANES and _QPLANES[0][1] == key) else None), key, made)]
     return made
 
@@ -177,11 +183,13 @@ def _maxsim_forward(Q, P, qmask, pmask, need_dq: bool, need_dp: bool):
     on, scored once per query row; trainable pages that came out of this package's l2_normalize: their planes ride along).
     -> (out, argmax or None, Q and P as the kernels took them: what a backward needs)."""
     P_caller = P                                      # what the prepared-pages cache is keyed on
-    if Q.dim() == 3 and P.dim() == 3 and Q.shape[-1] == P.shape[-1] and 0 < Q.shape[-1] < ops.D:
-        Q, P = ops.pad_width(Q), ops.pad_width(P)     # narrower embeddings ride on zero columns (exact); gradients are cut back
-    both_bf16 = P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16
-    frozen = (not need_dp and P.is_cuda and P.dim() == 3 and Q.dim() == 3 and P.shape[-1] == ops.D and Q.shape[-1] == ops.D
-              and (both_bf16 or P.dtype != torch.bfloat16) and not (both_bf16 and need_dq)
+    if (Q.dim() == 3 and P.dim() == 3 and Q.shape[-1] == P.shape[-1] and 0 < Q.shape[-1] <= ops.D_WIDE
+            and Q.shape[-1] not in (ops.D, ops.D_WIDE)):
+        Q, P = ops.pad_width(Q), ops.pad_width(P)     # widths between the kernels' 128 / 256 ride on zero columns (exact); gradients are cut back
+    wide = Q.dim() == 3 and Q.shape[-1] == ops.D_WIDE   # 129..256 columns: fp16 hi/lo planes x two column blocks, whatever the dtype
+    both_bf16 = P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16 and not wide
+    frozen = (not need_dp and P.is_cuda and P.dim() == 3 and Q.dim() == 3 and P.shape[-1] == Q.shape[-1] and Q.shape[-1] in (ops.D, ops.D_WIDE)
+              and (both_bf16 or wide or P.dtype != torch.bfloat16) and not (both_bf16 and need_dq)
               and P.shape[0] > 0 and P.shape[1] > 0
               and Q.shape[0] > 0 and Q.shape[1] > 0 and P.shape[1] <= 65535 and Q.shape[1] <= 65535)
     if frozen:
@@ -189,7 +197,7 @@ def _maxsim_forward(Q, P, qmask, pmask, need_dq: bool, need_dp: bool):
         planes, amax, tilemask, pageflags = _prepared_pages(P_caller, pmask)
         qplanes, qamax = (Q.contiguous()[None], None) if both_bf16 else _query_planes(Q)
         cache = None
-        if _SCORE_CACHE_BUDGET > 0 and not need_dq and Q.is_contiguous() and Q.dtype in (torch.float32, torch.bfloat16):
+        if _SCORE_CACHE_BUDGET > 0 and not need_dq and not wide and Q.is_contiguous() and Q.dtype in (torch.float32, torch.bfloat16):
             cache = _score_cache_for(_prepared_key(P_caller, pmask), P, Q)
         if cache is not None:
             out, arg = ops.maxsim_forward_cached(cache, Q, qplanes, qamax, planes, amax, qmask, tilemask, pageflags), None

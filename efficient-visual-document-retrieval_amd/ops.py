@@ -12,7 +12,8 @@ import torch
 
 from . import _lib as L
 
-D = 128
+D = 128                  # width of one column block (the ColPali / ColQwen projection width: every tuned instance)
+D_WIDE = 256             # two column blocks: the widest embedding the kernels score (fp16 hi/lo planes x 2 blocks, round 6)
 
 
 def _require_cuda(*tensors) -> torch.device:
@@ -42,16 +43,31 @@ def _mask_u8(m: Optional[torch.Tensor], shape, dev) -> Optional[torch.Tensor]:
     return m.to(device=dev).bool().contiguous()
 
 
+def kernel_width(d: int) -> int:
+    """Width the kernels score a d-wide embedding at: 128 (one column block) or 256 (two)."""
+    if d <= 0 or d > D_WIDE:
+        raise NotImplementedError(f"embedding width {d} unsupported (kernels are built for widths up to {D_WIDE})")
+    return D if d <= D else D_WIDE
+
+
 def pad_width(x: torch.Tensor) -> torch.Tensor:
-    """(..., d) -> (..., 128) with zero columns appended when d < 128 (the kernels are built for the ColPali / ColQwen
-    projection width; a zero column contributes an exact 0 to every dot product, so scores, arg-max and the first d columns
-    of every gradient are those of the narrow tensors).  Wider embeddings are not supported."""
+    """(..., d) -> (..., 128) for d <= 128, (..., 256) for 128 < d <= 256, with zero columns appended (a zero column contributes
+    an exact 0 to every dot product, so scores, arg-max and the first d columns of every gradient are those of the narrow
+    tensors).  The reference takes any width (evaluator/retrieval.py:173); wider than 256 is not supported here."""
     d = x.shape[-1]
-    if d == D:
-        return x
-    if d > D or d == 0:
-        raise NotImplementedError(f"embedding width {d} unsupported (kernels are built for widths up to {D})")
-    return torch.nn.functional.pad(x, (0, D - d))
+    w = kernel_width(d)
+    return x if d == w else torch.nn.functional.pad(x, (0, w - d))
+
+
+def split_wide(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(..., 256) -> ((4, ..., 128) fp16 planes, absmax word): `split_f32` of the two 128-column blocks under ONE power of two for
+    the whole tensor; plane index = 2 * (0 hi | 1 lo) + column block -- the layout evdr_maxsim_fwd_prepared takes as nplanes = 4."""
+    if x.shape[-1] != D_WIDE:
+        raise RuntimeError(f"split_wide needs rows of width {D_WIDE}")
+    lead = tuple(x.shape[:-1])
+    blocks = x.float().reshape(-1, 2, D).transpose(0, 1).contiguous()           # (column block, row, 128)
+    planes, amax = split_f32(blocks)                                           # (hi | lo, column block, row, 128)
+    return planes.view((4,) + lead + (D,)), amax
 
 
 def workspace(nbytes: int, dev) -> torch.Tensor:
@@ -160,6 +176,15 @@ def maxsim_forward(Q: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Tenso
         raise RuntimeError(f"zero-length token axis (Lq={lq}, Lp={lp})")
     if lp > 65535 or lq > 65535:
         raise NotImplementedError("token axes longer than 65535 are not supported")
+    if d == D_WIDE:
+        # 129..256 columns: every dtype is upcast like the reference does (evaluator/retrieval.py:176-177) and scored to fp32
+        # accuracy on four planes (fp16 hi/lo x two column blocks), through the prepared entry point
+        qp, qa = split_wide(Q)
+        pp, pa = split_wide(P)
+        tilemask, pageflags = pack_pmask(pmask, npg, lp, dev)
+        for cb in (0, 1):
+            flag_nonfinite(pp[cb], pmask, pageflags)                          # the hi planes of both column blocks
+        return maxsim_forward_prepared(qp, qa, pp, pa, qmask, tilemask, pageflags, want_argmax=want_argmax)
     lib = L.load()
     if Q.dtype == torch.bfloat16 and P.dtype == torch.bfloat16:
         dtype = L.EVDR_BF16
@@ -191,8 +216,10 @@ def maxsim_forward_prepared(qplanes: torch.Tensor, qamax: Optional[torch.Tensor]
     dev = _require_cuda(qplanes, pplanes)
     nplanes, nq, lq, _ = qplanes.shape
     _, npg, lp, _ = pplanes.shape
-    if pplanes.shape[0] != nplanes or (nplanes == 2) != (qplanes.dtype == torch.float16) or pplanes.dtype != qplanes.dtype:
-        raise RuntimeError("query and page planes must both be (1, ., ., 128) bf16 or both (2, ., ., 128) fp16")
+    if (nplanes not in (1, 2, 4) or pplanes.shape[0] != nplanes or (nplanes >= 2) != (qplanes.dtype == torch.float16)
+            or pplanes.dtype != qplanes.dtype):
+        raise RuntimeError("query and page planes must both be (1, ., ., 128) bf16, both (2, ., ., 128) fp16, or both (4, ., ., 128) "
+                           "fp16 (width 256: `split_wide`)")
     if pplanes.stride(3) != 1 or pplanes.stride(2) != D or not qplanes.is_contiguous():
         raise RuntimeError("planes must be dense in their last two dims (queries fully contiguous)")
     if out is None:
@@ -290,6 +317,9 @@ def maxsim_backward(g: torch.Tensor, Q: torch.Tensor, qmask: Optional[torch.Tens
     """A6: dP (np, lp, 128) fp32 from upstream g (nq, np) and the forward's argmax."""
     dev = _require_cuda(g, Q, argmax)
     nq, lq, d = Q.shape
+    if d == D_WIDE:
+        # the gather is linear in Q's columns: one launch per 128-column block, same arg-max and weights
+        return torch.cat([maxsim_backward(g, Q[..., cb * D:(cb + 1) * D], qmask, pmask, argmax, npg, lp) for cb in (0, 1)], dim=-1)
     lib = L.load()
     gc = g.float().contiguous()
     Qc = Q.float().contiguous()
@@ -601,6 +631,8 @@ def maxsim_backward_q(g: torch.Tensor, P: torch.Tensor, qmask: Optional[torch.Te
     Deterministic (per-segment partial sums added in a fixed order, no float atomics)."""
     dev = _require_cuda(g, P, argmax)
     npg, lp, d = P.shape
+    if d == D_WIDE:
+        return torch.cat([maxsim_backward_q(g, P[..., cb * D:(cb + 1) * D], qmask, pmask, argmax, nq, lq) for cb in (0, 1)], dim=-1)
     lib = L.load()
     gc, Pc = g.float().contiguous(), P.float().contiguous()
     qm = _mask_u8(qmask, (nq, lq), dev)

@@ -23,7 +23,9 @@
  *     touch the same buffers is the caller's (streams / events), as with any HIP launch; workspaces are per call.
  *     tests/cabi/cabi_threads.cpp: eight threads, one kernel family each, first launches racing, bit-equal to serial calls.
  *     Several processes per node (one per GPU: corpus.py / bench.py) are the multi-GPU form;
- *   - D (embedding width) must be 128 (ColPali / ColQwen projection width);
+ *   - D (embedding width) is 128 (ColPali / ColQwen projection width) for every entry point that takes `d`; wider
+ *     embeddings (up to 256) are scored through evdr_maxsim_fwd_prepared with nplanes = 4, and their gradients -- linear in the
+ *     columns -- by one evdr_maxsim_bwd / evdr_maxsim_bwd_q call per 128-column block (what the Python host shim does);
  *   - masks are one byte per token, 0 = masked (torch.bool storage);
  *   - dtype: EVDR_F32 inputs are scored to fp32 accuracy (fp16 hi/lo planes of the power-of-two-scaled
  *     tensors, 3 MFMA products, error below the rounding noise of an fp32 accumulation); EVDR_BF16
@@ -133,8 +135,12 @@ EVDR_API int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask,
                     void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Same computation on a PREPARED (resident) corpus: planes + packed masks made once with
- * evdr_split_f32 / evdr_pack_pmask.  nplanes = 1 (bf16 tensors as they are) or 2 (fp16 hi/lo planes of fp32
- * tensors, with the absmax words evdr_split_f32 produced for Q and P; NULL = planes are unscaled).  Q planes are
+ * evdr_split_f32 / evdr_pack_pmask.  nplanes = 1 (bf16 tensors as they are), 2 (fp16 hi/lo planes of fp32
+ * tensors, with the absmax words evdr_split_f32 produced for Q and P; NULL = planes are unscaled) or 4 (embeddings of
+ * width 256: the reference takes any width, evaluator/retrieval.py:173 -- the two 128-column blocks of each tensor as fp16 hi/lo
+ * planes under ONE absmax word per tensor, plane index = 2 * (0 hi | 1 lo) + column block, i.e. evdr_split_f32 of the tensor
+ * rearranged to (column block, row, 128); widths of 129..255 ride on zero columns; one query per wave, six plane products per
+ * k-step into one accumulator chain, same accuracy and NaN rules as nplanes = 2; evdr_flag_nonfinite once per hi plane).  Q planes are
  * (nplanes, nq, lq, 128); P planes are nplanes slabs `p_plane_stride` elements apart, each
  * (np, lp, 128) with `p_stride` elements between pages.  out row stride = out_stride floats, so a
  * shard can write its column block of a wider (nq, N) matrix.  This is the bench / retrieval

@@ -220,3 +220,25 @@ def trajectory_case(steps: int = 8):
         qmb[:, 28 - (s % 5):] = False
         batches.append((Qb, qmb))
     return batches, Pt, pmt, Pbar0, pms, hp
+
+
+def width_case(d: int):
+    """A1 + autograd at embedding width d (round 6: the reference takes any width, evaluator/retrieval.py:173; the kernels score
+    d <= 128 on one 128-column block and 128 < d <= 256 on two): ragged masks, an all-masked page, pages crossing several
+    tiles, queries with masked heads and tails."""
+    gen = torch.Generator().manual_seed(6000 + d)
+    Q = _unit(gen, 7, 20, d)
+    P = _unit(gen, 11, 75, d)
+    qm = torch.ones(7, 20, dtype=torch.bool)
+    qm[2, 13:] = False
+    qm[5, :3] = False
+    pm = torch.ones(11, 75, dtype=torch.bool)
+    pm[4] = False                           # all-masked page
+    pm[6, 40:] = False                      # ragged tail
+    pm[8, 5:60:7] = False                   # holes
+    pm[9, :33] = False                      # masked prefix (a whole tile and a bit)
+    # (no planted tie here: in fp32 two identical patch rows do not give bit-equal similarities in the reference's CPU einsum --
+    # the blocked GEMM sums them in different orders --, so which of them its max picks depends on chunk_p; exact ties are pinned
+    # on bf16-representable values by `small_case`)
+    g = torch.randn(7, 11, generator=gen)
+    return Q, P, qm, pm, g

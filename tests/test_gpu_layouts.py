@@ -72,7 +72,8 @@ def test_layouts_fp32(nq):
 def test_embedding_widths_below_128(d):
     """The reference scores any embedding width (evaluator/retrieval.py:166-213); the kernels are built for 128, and narrower
     embeddings ride on zero columns, which add exact zeros to every dot product: scores, arg-max and gradients (w.r.t. pages
-    and queries, cut back to d columns) against the oracle on the narrow tensors; the list scorer too.  Wider embeddings raise."""
+    and queries, cut back to d columns) against the oracle on the narrow tensors; the list scorer too.  Widths of 129..256 run on
+    two column blocks (tests/test_gpu_width.py); beyond 256 raises."""
     import evdr_amd  # noqa: F401
     from evdr_amd.evaluator.retrieval import BaseVisualRetrieverProcessor, score_multi_vector_masked
     gen = torch.Generator().manual_seed(300 + d)
@@ -104,5 +105,5 @@ def test_embedding_widths_below_128(d):
     got = BaseVisualRetrieverProcessor.score_multi_vector(qs, ps, batch_size=4, device=DEV)
     np.testing.assert_allclose(got.numpy(), O.maxsim_unmasked_lists(qs, ps, batch_size=4).numpy(), atol=1e-4, rtol=0)
     with pytest.raises(NotImplementedError):
-        score_multi_vector_masked(torch.zeros(2, 3, 256, device=DEV), torch.zeros(2, 5, 256, device=DEV),
+        score_multi_vector_masked(torch.zeros(2, 3, 257, device=DEV), torch.zeros(2, 5, 257, device=DEV),
                                   torch.ones(2, 3, device=DEV), torch.ones(2, 5, device=DEV))

@@ -32,6 +32,22 @@ def test_a1_small_forward_backward(golden, case):
     np.testing.assert_allclose(Pg.grad.numpy(), z["dP"], atol=1e-6, rtol=0)
 
 
+@pytest.mark.parametrize("d", [64, 200, 256])
+def test_a1_other_embedding_widths(golden, d):
+    """The oracle against the reference's own output at widths other than 128 (tests/golden/make_golden_width.py; the reference takes
+    the width from its tensors, evaluator/retrieval.py:173): scores, arg-max, dP and dQ."""
+    z = golden(f"a1_width{d}")
+    Q, P, qm, pm, g = R.width_case(d)
+    s, arg = O.maxsim_masked_argmax(Q, P, qm, pm)
+    np.testing.assert_allclose(s.numpy(), z["scores"], atol=2e-6, rtol=0)
+    assert np.array_equal(arg.numpy().astype(np.int32), z["argmax"])
+    Qg, Pg = Q.clone().requires_grad_(True), P.clone().requires_grad_(True)
+    (O.maxsim_masked(Qg, Pg, qm, pm) * g).sum().backward()
+    np.testing.assert_allclose(Pg.grad.numpy(), z["dP"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(Qg.grad.numpy(), z["dQ"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(O.maxsim_backward(g, Q, P, qm, pm).numpy(), z["dP"], atol=1e-6, rtol=0)
+
+
 def test_a1_known_answers(golden):
     z = golden("a1_small_ragged")
     Q, P, qm, pm, g = R.small_case("small_ragged")
