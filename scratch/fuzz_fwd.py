@@ -1,5 +1,6 @@
 """One-off fuzz of the forward kernels against the oracle: many seeds of tests/test_gpu_random_sweep.py's case generator plus
-1030-patch range/hole layouts with random query counts.  usage: python scratch/fuzz_fwd.py <first_seed> <count> [long]
+1030-patch range/hole layouts with random query counts; every fifth seed at another embedding width (round 6: 129..256 columns run on
+two column blocks, narrower ones on zero columns).  usage: python scratch/fuzz_fwd.py <first_seed> <count> [long]
 `long` (round 3): every case is a long-page case -- lp drawn from 1057 ... 65535 (random lengths, powers of two and their neighbours,
 the ABI bound), range / hole layouts whose range may start beyond patch 4095, few pages."""
 import os, sys, numpy as np, torch
@@ -33,6 +34,11 @@ for seed in range(s0, s0 + n):
         pm = (ar >= lo[:, None]) & (ar < hi[:, None])
         if seed % 2: pm[:, int(torch.randint(0, lp, (1,), generator=g))] = False      # one hole: mask words decide
         qm = torch.rand(nq, 32, generator=g) > 0.2
+    if seed % 5 == 4 and not LONG:                      # another embedding width: the same case re-drawn at d columns (fp32 and bf16 inputs)
+        g = torch.Generator().manual_seed(seed + 1)
+        d = [256, 200, 129, 255, 64, 256][seed % 6]
+        Q = torch.nn.functional.normalize(torch.randn(Q.shape[0], Q.shape[1], d, generator=g), dim=-1).bfloat16()
+        P = torch.nn.functional.normalize(torch.randn(P.shape[0], P.shape[1], d, generator=g), dim=-1).bfloat16()
     want, warg = O.maxsim_masked_argmax(Q.float(), P.float(), qm, pm)
     for am in (False, True):
         for Qx, Px in ((Q, P), (Q.float(), P.float())):
