@@ -49,6 +49,7 @@ _PREPARED_MAX_BYTES = 32 << 30         # of prepared planes in total (they are a
 def forget_prepared() -> None:
     _PREPARED.clear()
     _QPLANES.clear()
+    _PACKED.clear()
     ops._DERIVED.clear()
     _SCORE_CACHES.clear()
 
@@ -118,6 +119,9 @@ def _score_cache_for(key, P: torch.Tensor, Q: torch.Tensor):
 _tensor_key = ops.tensor_key           # None for None AND for inference tensors (no version counter: never cached)
 
 
+_LAST_KEY = None
+
+
 def _prepared_key(P: torch.Tensor, pmask: Optional[torch.Tensor]):
     return (_tensor_key(P), _tensor_key(pmask))
 
@@ -127,7 +131,8 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
     P is the CALLER's tensor (the cache is keyed on it and dies with it); embeddings narrower than 128 are padded here, on
     a miss only -- keyed on a padded temporary, every call would redo pad + split + mask packing + the non-finite scan and push a
     live entry out of the small LRU."""
-    key = _prepared_key(P, pmask)
+    global _LAST_KEY
+    key = _LAST_KEY = _prepared_key(P, pmask)           # (the score-row cache of the same call is keyed on it too: computed once)
     cacheable = key[0] is not None and (pmask is None or key[1] is not None)       # not under torch.inference_mode()
     hit = _PREPARED.get(key) if cacheable else None
     if hit is not None and hit[0]() is not None and (pmask is None or hit[1]() is not None):
@@ -155,6 +160,23 @@ def _prepared_pages(P: torch.Tensor, pmask: Optional[torch.Tensor]):
         while len(_PREPARED) > _PREPARED_MAX or sum(e[3] for e in _PREPARED.values()) > _PREPARED_MAX_BYTES:
             _PREPARED.popitem(last=False)
     return prep
+
+
+# The student's page mask is the same tensor step after step (mainv2_iter_distill_infonce.py:279,286 pass pmask_s every step): its
+# packed form (tile words + page flag words) is kept per mask tensor, keyed like everything else here (address, layout, version), and
+# every call gets its own copy of the small flag array, because the non-finite scan of the step's fresh planes ORs its findings into it.
+_PACKED: list = []                     # [(weakref(pmask), key, tilemask, pageflags)]: the last page mask that was packed
+
+
+def _packed_mask(pmask, npages: int, lp: int, dev):
+    key = _tensor_key(pmask)
+    if key is None:
+        return ops.pack_pmask(pmask, npages, lp, dev)
+    if _PACKED and _PACKED[0][1] == key and _PACKED[0][0]() is not None and _PACKED[0][2].device == dev:
+        return _PACKED[0][2], _PACKED[0][3].clone()
+    tilemask, pageflags = ops.pack_pmask(pmask, npages, lp, dev)
+    _PACKED[:] = [(weakref.ref(pmask, lambda _r: _PACKED.clear() if (_PACKED and _PACKED[0][1] == key) else None), key, tilemask, pageflags)]
+    return tilemask, pageflags.clone()
 
 
 _QPLANES: list = []                    # [(weakref(Q), key, (planes, absmax word))]: the last fp32 query batch that was split
@@ -198,7 +220,7 @@ def _maxsim_forward(Q, P, qmask, pmask, need_dq: bool, need_dp: bool):
         qplanes, qamax = (Q.contiguous()[None], None) if both_bf16 else _query_planes(Q)
         cache = None
         if _SCORE_CACHE_BUDGET > 0 and not need_dq and not wide and Q.is_contiguous() and Q.dtype in (torch.float32, torch.bfloat16):
-            cache = _score_cache_for(_prepared_key(P_caller, pmask), P, Q)
+            cache = _score_cache_for(_LAST_KEY, P, Q)        # the key _prepared_pages has just computed for (P_caller, pmask)
         if cache is not None:
             out, arg = ops.maxsim_forward_cached(cache, Q, qplanes, qamax, planes, amax, qmask, tilemask, pageflags), None
         else:
@@ -213,7 +235,7 @@ def _maxsim_forward(Q, P, qmask, pmask, need_dq: bool, need_dp: bool):
             derived = ops.planes_of(P)
         if derived is not None:
             planes, amax = derived
-            tilemask, pageflags = ops.pack_pmask(pmask, P.shape[0], P.shape[1], P.device)
+            tilemask, pageflags = _packed_mask(pmask, P.shape[0], P.shape[1], P.device)
             ops.flag_nonfinite(planes[0], pmask, pageflags)
             qplanes, qamax = _query_planes(Q)
             out, arg = ops.maxsim_forward_prepared(qplanes, qamax, planes, amax, qmask, tilemask, pageflags, want_argmax=True)

@@ -40,6 +40,8 @@ def _mask_u8(m: Optional[torch.Tensor], shape, dev) -> Optional[torch.Tensor]:
         return None
     if tuple(m.shape) != tuple(shape):
         raise RuntimeError(f"mask shape {tuple(m.shape)} does not match {tuple(shape)}")
+    if m.dtype is torch.bool and m.device == dev and m.is_contiguous():
+        return m                                        # the usual case, a dozen times per training step: no dispatcher round trips
     return m.to(device=dev).bool().contiguous()
 
 
