@@ -37,6 +37,21 @@ def test_cabi_from_several_host_threads(tmp_path):
     assert r.returncode == 0 and "cabi_threads OK" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
+def test_score_row_cache_and_subset_forward_from_plain_cpp(tmp_path):
+    """The round-6 entry points from a torch-free C++ program (tests/cabi/cabi_qcache.cpp): a resident bf16 corpus, the score-row
+    cache over three batches (all misses / all hits / half known: bit-equal to the plain forward, device-side miss counts 8 / 0 / 4),
+    the subset forward on a device-side list, a short workspace refused with a status code."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    libdir = os.path.join(ROOT, "efficient-visual-document-retrieval_amd")
+    exe = str(tmp_path / "cabi_qcache")
+    subprocess.run([hipcc, "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cabi", "cabi_qcache.cpp"),
+                    "-L", libdir, "-levdr", f"-Wl,-rpath,{libdir}", "-o", exe], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "cabi_qcache OK" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 def test_the_ctypes_stub_printed_in_integration_md_runs():
     """INTEGRATION.md §2 shows the reference-side binding a maintainer would add (a ctypes stub around evdr_maxsim_fwd).  The block
     is taken out of the document, pointed at the built library and executed: it must score like the oracle (no doc rot)."""
