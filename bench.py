@@ -285,6 +285,23 @@ def configs2_record(dev, corpus_pages_fn, n_pages: int = 6847, nq: int = 500, re
     return rec
 
 
+class _quiet_stdout:
+    """File descriptor 1 points at stderr while a process group is formed: Gloo's C++ side prints "[Gloo] Rank r is connected to ..."
+    lines to stdout, and stdout is where rank 0's ONE JSON line goes (the driver parses it)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._keep = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._keep, 1)
+        os.close(self._keep)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -326,9 +343,10 @@ def main():
     launcher = os.environ.get("EVDR_BENCH_LAUNCHER", "torchrun" if "WORLD_SIZE" in os.environ else "none")
     if args.rendezvous_only:
         if world > 1:
-            dist.init_process_group("gloo")
-            seen = torch.ones(1)
-            dist.all_reduce(seen)
+            with _quiet_stdout():
+                dist.init_process_group("gloo")
+                seen = torch.ones(1)
+                dist.all_reduce(seen)
             if rank == 0:
                 print(json.dumps({"rendezvous": "ok", "world_size": dist.get_world_size(), "ranks_seen": int(seen.item()),
                                   "launcher": launcher}), flush=True)
@@ -355,7 +373,9 @@ def main():
         # (0.8 MB per rank and step) -- a one-sided failure can no longer split the job between two backends -- and the line says
         # which it was.  The control group's timeout is longer than the data group's: a rank whose RCCL probe failed at once
         # waits there for the ranks whose probe is still running into its timeout.
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+        with _quiet_stdout():
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+            dist.all_reduce(torch.ones(1))                # (Gloo connects its pairs lazily: the chatter belongs in here)
         ok_mine, why = 1, None
         if backend == "nccl":
             # a ONE-SIDED RCCL failure (group creation or the probe raising on one rank only) leaves the peers blocked in the probe's
@@ -365,10 +385,11 @@ def main():
             # "no handling" -- a silent hang, not an exception.  The agreed gloo fallback below therefore covers the failures that RAISE
             # (every rank refusing, group creation failing everywhere); a one-sided hang ends the job.  Unrehearsed on a 1-GPU pool.
             try:
-                group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=240), device_id=dev)
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe, group=group)
-                torch.cuda.synchronize()
+                with _quiet_stdout():                   # (RCCL prints its version banner to stdout when the communicator is made)
+                    group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=240), device_id=dev)
+                    probe = torch.ones(1, device=dev)
+                    dist.all_reduce(probe, group=group)
+                    torch.cuda.synchronize()
                 ranks_seen = int(probe.item())
                 ok_mine = int(ranks_seen == world)
                 why = None if ok_mine else f"RCCL all-reduce saw {ranks_seen} of {world} ranks"

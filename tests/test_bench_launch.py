@@ -29,6 +29,7 @@ def test_self_launch_forms_world_of_n():
     assert r.returncode == 0, r.stderr
     rec = _last_json(r.stdout)
     assert rec == {"rendezvous": "ok", "world_size": 3, "ranks_seen": 3, "launcher": "self"}
+    assert r.stdout.strip().count("\n") == 0 and r.stdout.strip().startswith("{")      # stdout carries the JSON line and nothing else (Gloo's own chatter goes to stderr)
 
 
 def test_torchrun_form_still_works():
