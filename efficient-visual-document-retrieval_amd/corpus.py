@@ -32,9 +32,10 @@ class PageCorpus:
                  amax: Optional[torch.Tensor] = None):
         ok = planes.dim() == 4 and planes.shape[-1] == ops.D and (
             (planes.dtype == torch.bfloat16 and planes.shape[0] == 1) or
-            (planes.dtype == torch.float16 and planes.shape[0] == 2 and amax is not None))
+            (planes.dtype == torch.float16 and planes.shape[0] in (2, 4) and amax is not None))
         if not ok:
-            raise RuntimeError("planes must be (1, np, lp, 128) bf16, or (2, np, lp, 128) fp16 hi/lo with their absmax word")
+            raise RuntimeError("planes must be (1, np, lp, 128) bf16, (2, np, lp, 128) fp16 hi/lo or (4, np, lp, 128) fp16 hi/lo x two "
+                               "column blocks (width 256: ops.split_wide), the fp16 forms with their absmax word")
         self.planes = planes
         self.amax = amax                     # absmax word of the fp32 tensor the fp16 planes were split from
         self.tilemask = tilemask
@@ -52,12 +53,18 @@ class PageCorpus:
 
     @classmethod
     def from_tensor(cls, P: torch.Tensor, pmask: Optional[torch.Tensor] = None, idx_base: int = 0) -> "PageCorpus":
-        """P (np, lp, 128): bf16 is kept as one plane, anything else is treated as fp32 and split into fp16 hi/lo."""
+        """P (np, lp, d): at d = 128 bf16 is kept as one plane and anything else is treated as fp32 and split into fp16 hi/lo; narrower
+        embeddings ride on zero columns; 129 <= d <= 256 is kept as four planes (fp16 hi/lo x two column blocks, any input dtype)."""
         dev = ops._require_cuda(P)
         npg, lp, _ = P.shape
-        planes, amax = (P.contiguous()[None], None) if P.dtype == torch.bfloat16 else ops.split_f32(P)
+        P = ops.pad_width(P)
+        if P.shape[-1] == ops.D_WIDE:
+            planes, amax = ops.split_wide(P)
+        else:
+            planes, amax = (P.contiguous()[None], None) if P.dtype == torch.bfloat16 else ops.split_f32(P)
         tilemask, pageflags = ops.pack_pmask(pmask, npg, lp, dev)
-        ops.flag_nonfinite(planes[0], pmask, pageflags)          # once per corpus: NaN / Inf pages score NaN (evdr.h)
+        for hi in range(planes.shape[0] // 2 if planes.shape[0] > 1 else 1):       # the hi plane of every column block
+            ops.flag_nonfinite(planes[hi], pmask, pageflags)                       # once per corpus: NaN / Inf pages score NaN (evdr.h)
         return cls(planes, tilemask, pageflags, idx_base, amax)
 
     def shard(self, lo: int, hi: int) -> "PageCorpus":
@@ -65,6 +72,14 @@ class PageCorpus:
         return PageCorpus(self.planes[:, lo:hi], self.tilemask[lo:hi], self.pageflags[lo:hi], self.idx_base + lo, self.amax)
 
     def _query_planes(self, Q: torch.Tensor) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        if self.nplanes == 4:                             # a 256-wide corpus: queries of 129..256 columns, any dtype
+            if ops.kernel_width(Q.shape[-1]) != ops.D_WIDE:
+                raise RuntimeError(f"this corpus holds embeddings of width 129..256; got queries of width {Q.shape[-1]}")
+            return ops.split_wide(ops.pad_width(Q))
+        if Q.shape[-1] != ops.D:
+            Q = ops.pad_width(Q)
+            if Q.shape[-1] != ops.D:
+                raise RuntimeError(f"this corpus holds embeddings of width <= 128; got queries of width {Q.shape[-1]}")
         if self.nplanes == 1:
             if Q.dtype != torch.bfloat16:
                 raise RuntimeError("bf16 corpus needs bf16 queries (round them explicitly with .bfloat16(), or "

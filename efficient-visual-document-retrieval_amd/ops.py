@@ -113,7 +113,7 @@ def split_f32(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     bits of max|x|; keep it with the planes)."""
     dev = _require_cuda(x)
     if x.shape[-1] != D:
-        raise NotImplementedError(f"embedding width {x.shape[-1]} unsupported (kernels are built for {D})")
+        raise NotImplementedError(f"rows of width {x.shape[-1]}: this entry takes 128-wide rows (129..256 columns: `split_wide`; the scorers pad and split by themselves)")
     lib = L.load()
     xc = x.float().contiguous()
     rows = xc.numel() // D
@@ -131,7 +131,7 @@ def split_f32_segments(x: torch.Tensor, seg: int) -> Tuple[torch.Tensor, torch.T
     keeps its own absmax word: bit for bit the planes `split_f32(x[s * seg:(s + 1) * seg])` makes."""
     dev = _require_cuda(x)
     if x.shape[-1] != D:
-        raise NotImplementedError(f"embedding width {x.shape[-1]} unsupported (kernels are built for {D})")
+        raise NotImplementedError(f"rows of width {x.shape[-1]}: this entry takes 128-wide rows (129..256 columns: `split_wide`; the scorers pad and split by themselves)")
     xc = x.float().contiguous()
     n = xc.shape[0]
     per = (xc.numel() // D) // max(n, 1)                       # rows per leading entry

@@ -138,3 +138,27 @@ def test_a2_list_scorer_and_width_limits(ER, O):
     with pytest.raises(NotImplementedError):
         ER.score_multi_vector_masked(torch.randn(2, 4, 300, device=dev), torch.randn(3, 8, 300, device=dev),
                                      torch.ones(2, 4, dtype=torch.bool, device=dev), torch.ones(3, 8, dtype=torch.bool, device=dev))
+
+
+def test_resident_corpus_of_wide_pages(O):
+    """PageCorpus / ShardedRetriever on 200-wide pages (kept as four planes): scores against the oracle, the per-shard top-k + merge
+    equal to the single-shard ranking bit for bit, a width mismatch refused."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd.corpus import PageCorpus, merge_candidates
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(44)
+    P = torch.nn.functional.normalize(torch.randn(90, 130, 200, generator=gen), dim=-1)
+    Q = torch.nn.functional.normalize(torch.randn(12, 32, 200, generator=gen), dim=-1)
+    pm = torch.rand(90, 130, generator=gen) > 0.1
+    qm = torch.rand(12, 32, generator=gen) > 0.1
+    qm[:, 0] = True
+    corpus = PageCorpus.from_tensor(P.to(dev), pm.to(dev))
+    assert corpus.nplanes == 4
+    s = corpus.score(Q.to(dev), qm.to(dev))
+    np.testing.assert_allclose(s.cpu().numpy(), O.maxsim_masked(Q, P, qm, pm).numpy(), atol=1e-4, rtol=0)
+    ts, ti = corpus.topk(Q.to(dev), qm.to(dev), 10)
+    parts = [corpus.shard(lo, hi).topk(Q.to(dev), qm.to(dev), 10) for lo, hi in ((0, 31), (31, 64), (64, 90))]
+    ms, mi = merge_candidates(torch.cat([p[0] for p in parts], dim=1), torch.cat([p[1] for p in parts], dim=1), 10)
+    assert torch.equal(ms, ts) and torch.equal(mi, ti)
+    with pytest.raises(RuntimeError):
+        corpus.score(torch.randn(2, 32, 128, device=dev))
