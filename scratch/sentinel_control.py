@@ -16,6 +16,9 @@ Job A: 256 queries x 2048 pages x 1030 patches (staged kernel; the RAW fault liv
 Job B: 256 queries x 4096 pages x 200 patches (7 tiles: the flat 3-slot ring, where the WAR fault of build 2 lives; build 3's lives in job A's ring).
 Each build runs in a child process (one library handle per process).  What the control shows: how often a real ring race is
 visible WITHOUT the poison (the blind spot of bit-compare stress loops) and WITH it.
+Where the builds live (round 6): the product and its sentinel twin in the package directory; every deliberately racing build under
+scratch/_variants/faults/ (`python -m evdr_amd.build --ring-fault[-war|-war2|-war2-held] [--sentinel]`), which .gitignore AND
+.gpurunignore list -- a control run on a GPU box takes the `scratch/_variants/faults/` line out of .gpurunignore for that one call.
 usage: python scratch/sentinel_control.py            (parent: runs the children)
        python scratch/sentinel_control.py <libname>  (child)"""
 import os
