@@ -171,7 +171,8 @@ int evdr_maxsim_fwd(const void* Q, const void* P, const uint8_t* qmask, const ui
                     uint16_t* argmax_or_null, int64_t nq, int64_t lq, int64_t np, int64_t lp, int64_t d, int dtype,
                     const int64_t* strides_or_null, void* workspace, size_t workspace_bytes, void* hip_stream) {
     if (int rc = check_common(nq, lq, np, lp)) return rc;
-    if (d != EVDR_D) return fail(EVDR_ERR_SHAPE, "embedding width %lld unsupported (kernels are built for 128)", (long long)d);
+    if (d != EVDR_D)
+        return fail(EVDR_ERR_SHAPE, "embedding width %lld: this entry takes width 128 (widths up to 256: evdr_maxsim_fwd_prepared with nplanes = 4)", (long long)d);
     if (dtype != EVDR_F32 && dtype != EVDR_BF16) return fail(EVDR_ERR_ARG, "dtype must be EVDR_F32 or EVDR_BF16");
     if (nq == 0 || np == 0) return EVDR_OK;                      // empty score matrix
     if (lq == 0 || lp == 0) return fail(EVDR_ERR_SHAPE, "zero-length token axis (lq=%lld lp=%lld)", (long long)lq, (long long)lp);
