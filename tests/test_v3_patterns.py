@@ -54,6 +54,28 @@ def test_hip_path_reproduces_the_reference_steps(golden):
 
 
 @pytest.mark.gpu
+def test_hip_path_with_the_score_row_cache_on_reproduces_the_reference_steps(golden, monkeypatch):
+    """The same four script steps with `evaluator.retrieval.enable_score_cache()` (the one-line switch of INTEGRATION.md §1): every
+    no-grad scoring of a frozen tensor with 2..32-token queries goes through the device-side cache (noise / mixup queries are new rows
+    every call, the single-token virtual queries bypass it) -- the fixtures of the reference's own train_one_step functions hold with
+    the switch on, and the cached forward really was the path taken."""
+    import evdr_amd  # noqa: F401
+    from evdr_amd import ops
+    from evdr_amd.evaluator import retrieval as ER
+    calls = []
+    real = ops.maxsim_forward_cached
+    monkeypatch.setattr(ops, "maxsim_forward_cached", lambda cache, *a, **k: (calls.append(int(a[0].shape[0])), real(cache, *a, **k))[1])
+    ER.forget_prepared()
+    ER.enable_score_cache(64 << 20)
+    try:
+        _run_all(V.hip_backend(), golden, grad_atol=1e-6)
+    finally:
+        ER.disable_score_cache()
+        ER.forget_prepared()
+    assert len(calls) >= 4 and all(n > 0 for n in calls), calls          # at least the teacher call of each of the four steps
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["infonce_supervised_loss", "score_preserving_loss", "pairwise_distillation_loss",
                                   "listwise_distillation_loss", "lambda_loss", "ranknce_loss"])
 def test_each_secondary_loss_drives_the_hip_backward(name):
