@@ -595,12 +595,14 @@ def test_stream_adamw_equals_torch_adamw(dev, shape):
     assert torch.isfinite(d).all() and not torch.equal(d.detach(), x0)
 
 
-@pytest.mark.parametrize("mode", ["call_pattern", "fused"])
-def test_a7_eight_step_trajectory(golden, dev, ER, mode):
+@pytest.mark.parametrize("mode", ["call_pattern", "call_pattern_cached", "fused"])
+def test_a7_eight_step_trajectory(golden, dev, ER, mode, request):
     """Eight consecutive steps against the trajectory the reference's OWN train_one_step produced
     (tests/golden/make_golden_trajectory.py): every loss, the parameters after steps 1 / 4 / 8 and AdamW's moments --
     through the drop-in modules used like the script (autograd + utils.set_optimizer) and through the fused step.  Pins the
-    optimizer's step count / bias corrections, the moments and the feedback of updated pages into the next forward."""
+    optimizer's step count / bias corrections, the moments and the feedback of updated pages into the next forward.
+    `call_pattern_cached` (round 6): the same script steps with `enable_score_cache()` after one pass over the query batches (an
+    epoch that has filled the cache): all eight teacher calls are served from the device-side table -- same trajectory."""
     from evdr_amd import driver
     from evdr_amd.utils.preprocess_data import l2_normalize
     from evdr_amd.utils.utils import set_optimizer
@@ -609,7 +611,16 @@ def test_a7_eight_step_trajectory(golden, dev, ER, mode):
     Pt, pmt, Pbar0, pms = Pt.to(dev), pmt.to(dev), Pbar0.to(dev), pms.to(dev)
     Ptn = l2_normalize(Pt * pmt.unsqueeze(-1)).detach()
     big = torch.from_numpy(z["big"])
-    if mode == "call_pattern":
+    if mode == "call_pattern_cached":
+        ER.forget_prepared()
+        ER.enable_score_cache(32 << 20)
+        request.addfinalizer(lambda: (ER.disable_score_cache(), ER.forget_prepared()))      # also when an assertion below fails
+        with torch.no_grad():
+            for Qb, qmb in batches:                                 # the first epoch: every query row of the run is scored once
+                ER.score_multi_vector_masked(Qb.to(dev), Ptn, qmb.to(dev), pmt)
+        cache = next(c for c in ER._SCORE_CACHES.values() if c is not None)
+        assert int(cache.n_entries.item()) == 4 * len(batches)
+    if mode in ("call_pattern", "call_pattern_cached"):
         param = torch.nn.Parameter(Pbar0 * pms.unsqueeze(-1))
         opt = set_optimizer("adamw", param, hp["lr"], hp["wd"])
         step = lambda Qb, qmb: driver.train_one_step(Qb.to(dev), qmb.to(dev), Ptn, pmt, param, pms, opt, hp["temp"])
@@ -622,6 +633,8 @@ def test_a7_eight_step_trajectory(golden, dev, ER, mode):
     for i, (Qb, qmb) in enumerate(batches, 1):
         loss = step(Qb, qmb)
         np.testing.assert_allclose(loss, z["losses"][i - 1], rtol=2e-5, err_msg=f"step {i}")
+        if mode == "call_pattern_cached":
+            assert int(cache.count.item()) == 0, i                 # nothing was scored: all four rows came out of the cache
         if i in (1, 4, 8):
             d = (cur()[0].cpu() - torch.from_numpy(z[f"param_after_{i}"])).abs()
             # tight wherever the reference's own gradient was well above its summation noise (or exactly zero) in every step;
@@ -631,6 +644,8 @@ def test_a7_eight_step_trajectory(golden, dev, ER, mode):
     _, ea, es = cur()
     np.testing.assert_allclose(ea.cpu().numpy()[z["big"]], z["exp_avg"][z["big"]], atol=2e-6)
     np.testing.assert_allclose(es.cpu().numpy()[z["big"]], z["exp_avg_sq"][z["big"]], atol=1e-9, rtol=2e-3)
+    if mode == "call_pattern_cached":
+        assert int(cache.n_entries.item()) == 4 * len(batches)
 
 
 def test_stream_adamw_takes_torchs_step_whole_when_anything_is_ineligible(dev):
