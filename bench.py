@@ -86,6 +86,18 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("EVDR_CPU_THREADS", "16"))))
 
 
+def cpu_model() -> str:
+    """The host CPU the baseline legs ran on ("core count and CPU model printed in the report")."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline_leg(dev_corpus_slice: torch.Tensor, Qdev: torch.Tensor, reps: int = 3):
     """The reference's scorer as restated in oracle/ (torch fp32 on the host, chunk_p=64), on a bounded slice of the
     SAME workload: 32 queries x 2048 pages, median of `reps` passes (about 15 s of host work in all).  A
@@ -105,7 +117,7 @@ def cpu_baseline_leg(dev_corpus_slice: torch.Tensor, Qdev: torch.Tensor, reps: i
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
     pairs = Q.shape[0] * P.shape[0]
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{Q.shape[0]} queries x {P.shape[0]} pages of the same corpus, chunk_p=64, torch fp32 CPU, median of "
                       f"{reps} passes ({', '.join(f'{t:.2f}' for t in times)} s), {cores} threads"}, s
 

@@ -317,7 +317,7 @@ def cpu_baseline(inp, n_pages: int, reps: int = 1):
         loss_c = O.distill_train_step(Qc, qmc, Ptc, pmtc, Pbc, pmsc, 0.1, 1e-3, 1e-2)[0]
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
-    rec = {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+    rec = {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "cpu_model": HB.cpu_model(), "kind": "port",
            "sample": f"{reps} step(s) of the oracle at B={B}, {n_pages} of the {N} pages (teacher {LT}, student {LS} patches), torch fp32 "
                      f"CPU, {dt:.2f} s per step, {cores} threads",
            "sample_pages": n_pages, "est_steps_per_sec_at_full_pages": (1.0 / dt) * n_pages / N, "loss": float(loss_c)}

@@ -85,7 +85,7 @@ def test_committed_bench_line_follows_the_contract():
         t = json.loads(raw)
         assert t["kernel"] == r["kernel"] and t["queries"] == rec["config"]["queries_per_step"] and t["pages_per_gpu"] == rec["config"]["pages"]
         assert r["traffic"] == t["hbm_bytes_per_launch"] >= r["algorithmic_bytes_per_launch"]
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_summary.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_summary.json")))
         assert pmc["hbm_bytes_per_launch"] == t["hbm_bytes_per_launch"]
     assert "INSIDE the timed region" in r["kernel_ms_basis"] or "inside the timed region" in r["kernel_ms_basis"]
     stats = open(os.path.join(ROOT, "profiles", "r06_bench_kernel_stats.csv")).read().splitlines()
